@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- the S-BLAS CSR SpMM hot path on MI355X, measured as BASELINE.json asks.
+
+Metric    : SpMM GFLOP/s (2*nnz*N / t) + achieved HBM GB/s, CSR x dense, N = 64 columns per GPU, fp64.
+Workload  : BASELINE config 3 -- "nd24k" SpMM method 1, N = 64, alpha = beta = 1.  The SuiteSparse file is not
+            in the image and cannot be fetched, so the default input is the synthetic stand-in of
+            s-blas_amd/python/sblas_amd/synth.py (72 000 x 72 000, 399 nnz/row = 28 728 000 nnz, band +-2000,
+            seed 211); pass --matrix file.mtx to use a real MatrixMarket file instead.
+A step    : one full pass of the hot path through the C ABI on device-resident inputs:
+            stage 1 (B -> row-major staging copy) + stage 2 (row-panel SpMM, alpha/beta fused).
+Multi-GPU : one process per GPU.  Method 1 partitions the dense columns and has no exchange step
+            (spmm.h:83-161), so rank r multiplies the full A by its own 64-column block: per-GPU work is fixed,
+            "scaling": "weak", no collective in the data path.  With --gpus > 1 the same run ALSO times method 2
+            (row-block A, RCCL all-reduce of the partial C, fused axpby; spmm.h:163-284) on N = 64 total columns
+            and reports it under "method2" (strong scaling, merge time separate) -- informational.
+Output    : exactly one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "s-blas_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(rows, cols, nnz, n, beta_nonzero=True):
+    """nnz*(4+8) + (M+1)*4 + 8*K*N + (16 or 8)*M*N."""
+    return nnz * 12 + (rows + 1) * 4 + 8 * cols * n + (16 if beta_nonzero else 8) * rows * n
+
+
+def load_workload(args):
+    import sblas_amd as S
+    from sblas_amd import synth
+    if args.matrix:
+        rows, cols, nnz, _, rp, ci, v = S.read_mtx(args.matrix)
+        name = os.path.basename(args.matrix)
+    else:
+        rows, (rp, ci, v) = synth.nd24k_like(scale=args.scale)
+        cols, nnz = rows, int(rp[-1])
+        name = "nd24k-like synthetic (M=K=%d, %d nnz/row, band +-2000, seed 211)" % (rows, 399)
+    return name, rows, cols, nnz, rp, ci, v
+
+
+def cpu_baseline(rows, cols, n, rp, ci, v, Bh, budget_s):
+    """The oracle (CPU restatement of sblas_spmm_csr_cpu, spmm.h:56-68) on this host, one thread, same inputs.
+    Runs whole passes over the workload until ~budget_s of CPU time has been spent (at least one)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    nnz = int(rp[-1])
+    C = np.ones(rows * n)
+    # calibrate on 1/16 of the rows, then pick the number of full passes
+    r_cal = max(1, rows // 16)
+    t0 = time.perf_counter()
+    O.spmm_rows(0, r_cal, rows, cols, n, rp, ci, v, Bh, C, 1.0, 1.0)
+    t_cal = time.perf_counter() - t0
+    est_full = t_cal * rows / r_cal
+    passes = int(max(1, min(8, budget_s // max(est_full, 1e-9))))
+    if est_full > 2 * budget_s:                     # huge matrix: a row prefix instead of full passes
+        r_end = max(r_cal, int(rows * budget_s / est_full))
+        C = np.ones(rows * n)
+        t0 = time.perf_counter()
+        O.spmm_rows(0, r_end, rows, cols, n, rp, ci, v, Bh, C, 1.0, 1.0)
+        dt = time.perf_counter() - t0
+        flops = 2.0 * float(rp[r_end]) * n
+        sample = "rows [0,%d) of %d, one pass" % (r_end, rows)
+    else:
+        C = np.ones(rows * n)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            O.spmm(rows, cols, n, rp, ci, v, Bh, C, 1.0, 1.0)
+        dt = time.perf_counter() - t0
+        flops = 2.0 * nnz * n * passes
+        sample = "%d full pass(es) of the same workload (all %d rows)" % (passes, rows)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": round(flops / dt / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": sample, "seconds": round(dt, 2), "host_cpu": model, "host_threads_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ncols", type=int, default=64, help="dense columns per GPU (method 1)")
+    ap.add_argument("--matrix", type=str, default=None, help="MatrixMarket file instead of the synthetic stand-in")
+    ap.add_argument("--scale", type=float, default=1.0, help="row-count scale of the synthetic stand-in (rehearsal only)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--no-method2", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sblas_amd as S
+    S.lib()   # fail loudly if the HIP library is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    name, rows, cols, nnz, rp, ci, v = load_workload(args)
+    n = args.ncols
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rowptr, colidx, val = d(rp), d(ci), d(v)
+    gen = torch.Generator(device="cpu").manual_seed(211 + rank)
+    Bh = torch.rand(cols * n, dtype=torch.float64, generator=gen)
+    B = Bh.to(dev)
+    C = torch.ones(rows * n, dtype=torch.float64, device=dev)
+    ldbt = int(S.lib().sblas_hip_spmm_ldbt(n))
+    Bt = torch.empty(cols * ldbt, dtype=torch.float64, device=dev)   # the C ABI's workspace
+
+    def step():
+        # == sblas_hip_spmm_csr_f64_i32: the same two launches, issued separately only so that an event can
+        # sit between them (per-kernel timing for the roofline object)
+        S.dense_to_rowmajor(cols, n, B, cols, Bt)
+        S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        S.dense_to_rowmajor(cols, n, B, cols, Bt)
+        ev[k][1].record()
+        S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
+        ev[k][2].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    t_stage1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    t_stage2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+
+    # correctness guard on this rank's result: C = 1 + (warmup+steps) * A*B on 64 sampled rows vs the oracle
+    total_steps = args.warmup + args.steps
+    check = None
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_py as O
+        r0 = rows // 3
+        ref = np.zeros(rows * n)
+        O.spmm_rows(r0, r0 + 64, rows, cols, n, rp, ci, v, Bh.numpy(), ref, 1.0, 0.0)
+        got = C.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
+        want = 1.0 + total_steps * ref.reshape(n, rows)[:, r0:r0 + 64]
+        check = bool(np.allclose(got, want, rtol=1e-9, atol=1e-9))
+        if not check:
+            raise SystemExit("bench result does not match the oracle: max diff %g" % np.abs(got - want).max())
+
+    flops_step = 2.0 * nnz * n                      # per GPU
+    value = world * flops_step * args.steps / elapsed / 1e9
+    alg = algorithmic_bytes(rows, cols, nnz, n, True)
+    out = {
+        "metric": "SpMM GFLOP/s (2*nnz*N/t), CSR x dense N=64, fp64",
+        "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
+        "config": {"workload": "SpMM method-1 (dense-B column partition), %s, nnz=%d, N=%d columns per GPU, alpha=beta=1, "
+                               "inputs resident in HBM; step = B->row-major staging + row-panel SpMM" % (name, nnz, n),
+                   "rows": rows, "cols": cols, "nnz": nnz, "n_cols_per_gpu": n, "parallelism": "method1-colblock x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "spmm_rowpanel_kernel",
+                     "achieved": round(alg / t_stage2 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / t_stage2 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_stage2 * 1e3, 5),
+                     "staging_kernel_ms": round(t_stage1 * 1e3, 5),
+                     "kernel_gflops": round(flops_step / t_stage2 / 1e9, 1)},
+        "hbm_gbs_whole_step": round(alg / (elapsed / args.steps) / 1e9, 1),
+        "oracle_check": check,
+    }
+
+    # ---- method 2 (row-block A + RCCL merge), informational, N total = ncols ---------------------------------
+    if world > 1 and not args.no_method2:
+        part = S.partition_nnz(rp, world, rank)
+        lo, k = part["first_nnz"], part["nnz"]
+        rp_i, ci_i, v_i = d(part["rowptr"]), colidx[lo:lo + k].contiguous(), val[lo:lo + k].contiguous()
+        m_i = len(part["rowptr"]) - 1
+        gen0 = torch.Generator(device="cpu").manual_seed(211)
+        B2 = torch.rand(cols * n, dtype=torch.float64, generator=gen0).to(dev)     # replicated B
+        C2 = torch.ones(rows * n, dtype=torch.float64, device=dev)
+        Ccopy = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+        e = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+        def step2(k=None):
+            Ccopy.zero_()                                     # spmm.h:182-183 (zero buffer), on device
+            if k is not None: e[k][0].record()
+            S.dense_to_rowmajor(cols, n, B2, cols, Bt)
+            S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 1.0, Ccopy, rows, c_offset=part["start_row"])
+            if k is not None: e[k][1].record()
+            dist.all_reduce(Ccopy)                            # spmm.h:260-262, RCCL over xGMI
+            if k is not None: e[k][2].record()
+            S.axpby(rows * n, 1.0, Ccopy, 1.0, C2)            # spmm.h:283 -> kernel.h:27-38
+            if k is not None: e[k][3].record()
+
+        for _ in range(args.warmup):
+            step2()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step2(k)
+        torch.cuda.synchronize()
+        barrier()
+        el2 = time.perf_counter() - t0
+        t = torch.tensor([el2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        out["method2"] = {
+            "scaling": "strong", "n_total_cols": n, "gflops": round(flops_step * args.steps / el2 / 1e9, 2),
+            "ms_per_step": round(el2 / args.steps * 1e3, 5),
+            "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e])), 5),
+            "ms_allreduce": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e])), 5),
+            "ms_axpby": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e])), 5),
+            "allreduce_payload_bytes": rows * n * 8,
+            "note": "rank-0 stage times; merge = torch.distributed all_reduce (RCCL) on the full M x N buffer as spmm.h:260-262",
+        }
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(rows, cols, n, rp, ci, v, Bh.numpy(), args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None   # reported at N=1 only
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

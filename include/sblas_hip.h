@@ -1,0 +1,144 @@
+/*
+ * sblas_hip.h -- C ABI of libsblas_hip.so, the MI355X (gfx950) core of the S-BLAS CSR
+ * SpMV / SpMM hot path.
+ *
+ * The reference (tartarughina/S-BLAS) has no FFI: its boundary for this path is the set of
+ * cuSPARSE / NCCL / CUDA-runtime calls made by the header templates sblas_spmm_csr_v1/_v2 and
+ * sblas_spmv_csr_v1.  Every entry point below replaces one of those call sites and takes the
+ * same information the replaced call received (plain pointers and sizes, no C++ or torch
+ * types).  The header-template layer in s-blas_amd/include/ (sblas.h, matrix.h, spmm.h, spmv.h)
+ * forwards to these functions; INTEGRATION.md shows the binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - all array arguments of the *_hip_* compute functions are DEVICE pointers on device `dev`
+ *     (dev < 0: use the calling thread's current device);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the device's null stream); nothing in the
+ *     compute functions allocates, frees or synchronises, so they are graph-capturable;
+ *   - CSR is base-0, int32 indices, fp64 values; `rowptr` is relative to the colidx/val pointers
+ *     that are passed (so the re-based row-block slices of method 2 work as they are);
+ *   - dense B / C are COLUMN-major with leading dimensions ldb / ldc (the only layout the
+ *     reference's GPU paths accept: spmm.h:91-98, :171-178);
+ *   - return value 0 = success, otherwise one of SBLAS_E_* (see sblas_hip_error_string).
+ */
+#ifndef SBLAS_HIP_H
+#define SBLAS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBLAS_OK 0
+#define SBLAS_E_INVALID 1   /* bad argument (null pointer, negative size, ld too small) */
+#define SBLAS_E_HIP 2       /* a HIP runtime call or kernel launch failed              */
+#define SBLAS_E_WORKSPACE 3 /* workspace missing or too small                          */
+#define SBLAS_E_RCCL 4      /* RCCL unavailable or a collective failed                 */
+#define SBLAS_E_IO 5        /* MatrixMarket file could not be read / parsed            */
+#define SBLAS_E_NOGPU 6     /* no HIP device visible                                   */
+
+int sblas_hip_version(void);
+const char *sblas_hip_error_string(int code);
+/* Number of visible HIP devices (0 when none / no driver).  Never initialises a context. */
+int sblas_hip_device_count(void);
+
+/* ---------------------------------------------------------------------------------------
+ * SpMM:  C = alpha * A * B + beta * C        A: rows x cols CSR, B: cols x n, C: rows x n
+ * Replaces cusparseSpMM_bufferSize + cusparseSpMM (NON_TRANSPOSE, ALG_DEFAULT, col-major) at
+ *   spmm.h:134-149  (method 1: full A, B/C column block of n_i columns, real alpha/beta)
+ *   spmm.h:239-251  (method 2: re-based row block A_i, C = Ccopy + start_row, ldc = M, alpha=beta=1)
+ * The workspace plays the role of cuSPARSE's externalBuffer (spmm.h:140-141, :245-246): it
+ * holds the row-major staging copy of B that the kernels gather from.
+ * ------------------------------------------------------------------------------------- */
+size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n);
+
+int sblas_hip_spmm_csr_f64_i32(int dev, void *stream,
+                               int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, const double *val,
+                               const double *B, int64_t ldb, int64_t n,
+                               double alpha, double beta,
+                               double *C, int64_t ldc,
+                               void *workspace, size_t workspace_bytes);
+
+/* The two stages of the call above, exposed so that a caller that multiplies the same B more
+ * than once (method 2 keeps B resident) or wants per-stage timing can drive them itself:
+ *   stage 1: Bt (cols x ldbt row-major, zero padded) <- B (cols x n col-major)
+ *   stage 2: the row-panel SpMM kernel reading Bt.
+ * ldbt = sblas_hip_spmm_ldbt(n). */
+int64_t sblas_hip_spmm_ldbt(int64_t n);
+int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n,
+                                    const double *B, int64_t ldb, double *Bt, int64_t ldbt);
+int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
+                                         int64_t rows, int64_t cols, int64_t nnz,
+                                         const int32_t *rowptr, const int32_t *colidx,
+                                         const double *val,
+                                         const double *Bt, int64_t ldbt, int64_t n,
+                                         double alpha, double beta, double *C, int64_t ldc);
+
+/* ---------------------------------------------------------------------------------------
+ * SpMV:  y = alpha * A * x + beta * y
+ * Replaces cusparseSpMV_bufferSize + cusparseSpMV at spmv.h:94-106 (no workspace is needed).
+ * ------------------------------------------------------------------------------------- */
+int sblas_hip_spmv_csr_f64_i32(int dev, void *stream,
+                               int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, const double *val,
+                               const double *x, double alpha, double beta, double *y);
+
+/* ---------------------------------------------------------------------------------------
+ * y = beta * y + alpha * x   (elementwise, n elements)
+ * Replaces the denseVector_plusEqual_denseVector launches at matrix.h:613-625 and :714-726
+ * (kernel.h:27-38).  Note the argument order mirrors the kernel: y is updated in place.
+ * ------------------------------------------------------------------------------------- */
+int sblas_hip_axpby_f64(int dev, void *stream, int64_t n,
+                        double alpha, const double *x, double beta, double *y);
+
+/* ---------------------------------------------------------------------------------------
+ * Partial-result merge over the GPUs of one node (RCCL over xGMI).
+ * Replaces ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy at
+ *   spmm.h:179-181,189,260-262,279 and spmv.h:43-45,58,115-118,134.
+ * One process drives n_gpu devices (the reference's process model); the communicator set is
+ * created once and reused (sblas_hip_comm_get caches per device list).  RCCL is dlopen'ed on
+ * first use so that the library loads on machines without it.
+ * When several ranks are mapped onto ONE physical device (devs[] all equal; used to rehearse
+ * the g-way paths on a single-GPU box) the sum is done by an on-device kernel instead.
+ * ------------------------------------------------------------------------------------- */
+int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out);
+void sblas_hip_comm_release_all(void);
+/* In-place sum all-reduce of `count` doubles; bufs[r] / streams[r] belong to rank r.
+ * Issues the collective for every rank (grouped) from the calling thread. */
+int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void *const *streams,
+                                int64_t count);
+
+/* ---------------------------------------------------------------------------------------
+ * Host-side placement arithmetic (pure functions, no GPU needed).
+ * ------------------------------------------------------------------------------------- */
+/* csr_findRowIdxUsingNnzIdx, utility.h:292-300 (same answer, O(log M)). */
+int32_t sblas_find_row_of_nnz(const int32_t *rowptr, int32_t rows, int32_t nnz_idx);
+
+/* nnz-balanced row-block partition of CsrSparseMatrix::sync2gpu(segment), matrix.h:356-375.
+ * Uses the exact integer ceil((nnz)/g) (the reference's float ceil drops nonzeros above 2^24;
+ * both agree below).  rebased_rowptr may be NULL; otherwise it must hold stop-start+2 ints.
+ * Returns the number of row pointers (stop_row - start_row + 2) or a negative value. */
+int64_t sblas_partition_nnz(const int32_t *rowptr, int32_t rows, int32_t nnz, int n_gpu, int i_gpu,
+                            int32_t *start_row, int32_t *stop_row, int32_t *nnz_i,
+                            int64_t *first_nnz, int32_t *rebased_rowptr);
+
+/* Leading-dimension block partition of DenseMatrix::sync2gpu(segment), matrix.h:554-568. */
+int sblas_partition_dense(int64_t first_order, int n_gpu, int i_gpu,
+                          int64_t *offset, int64_t *dim);
+
+/* ---------------------------------------------------------------------------------------
+ * MatrixMarket -> CSR (host).  Same observable result as mmio_info / mmio_data
+ * (mmio_highlevel.h:7-127, :130-281): file order preserved inside a row, symmetric/hermitian
+ * mirrored, skew treated as general, pattern -> 1.0, complex -> real part, 1-based -> 0-based.
+ * Single pass over the text, arrays sized by the caller from sblas_mm_read_info.
+ * ------------------------------------------------------------------------------------- */
+int sblas_mm_read_info(const char *path, int32_t *rows, int32_t *cols, int32_t *nnz,
+                       int32_t *is_symmetric);
+int sblas_mm_read_csr(const char *path, int32_t *rowptr, int32_t *colidx, double *val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBLAS_HIP_H */

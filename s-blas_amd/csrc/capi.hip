@@ -1,0 +1,164 @@
+// capi.hip -- the extern "C" surface declared in include/sblas_hip.h (compute entry points).
+// Argument checking happens here, on the host, before any kernel is launched: a bad shape must
+// come back as SBLAS_E_INVALID, never as a faulting wave.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include "../../include/sblas_hip.h"
+#include "kernels.h"
+
+namespace {
+
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        if (dev < 0) return;
+        err = hipGetDevice(&prev);
+        if (err != hipSuccess) return;
+        if (prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceScope()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+inline bool csr_args_ok(int64_t rows, int64_t cols, int64_t nnz, const void *rowptr, const void *colidx,
+                        const void *val)
+{
+    if (rows < 0 || cols < 0 || nnz < 0) return false;
+    if (rows > INT_MAX - 64 || cols > INT_MAX || nnz > INT_MAX) return false; // int32 index API
+    if (!rowptr) return false;
+    if (nnz > 0 && (!colidx || !val)) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+int sblas_hip_version(void) { return 100; }
+
+const char *sblas_hip_error_string(int code)
+{
+    switch (code) {
+    case SBLAS_OK: return "success";
+    case SBLAS_E_INVALID: return "invalid argument";
+    case SBLAS_E_HIP: return "HIP runtime / kernel launch failure";
+    case SBLAS_E_WORKSPACE: return "workspace missing or too small";
+    case SBLAS_E_RCCL: return "RCCL unavailable or collective failed";
+    case SBLAS_E_IO: return "MatrixMarket read/parse failure";
+    case SBLAS_E_NOGPU: return "no HIP device";
+    default: return "unknown sblas error";
+    }
+}
+
+int sblas_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t sblas_hip_spmm_ldbt(int64_t n)
+{
+    if (n <= 0) return 0;
+    if (n <= 8) return 8;
+    if (n <= 16) return 16;
+    if (n <= 32) return 32;
+    return (n + 63) / 64 * 64;
+}
+
+size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
+{
+    (void)rows;
+    (void)nnz;
+    if (cols <= 0 || n <= 0) return 0;
+    return (size_t)cols * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
+}
+
+int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n, const double *B,
+                                    int64_t ldb, double *Bt, int64_t ldbt)
+{
+    if (cols < 0 || n < 0) return SBLAS_E_INVALID;
+    if (cols == 0 || n == 0) return SBLAS_OK;
+    if (!B || !Bt || ldb < cols || ldbt < n || ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_dense_to_rowmajor((hipStream_t)stream, cols, n, B, ldb, Bt, ldbt) == hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                                         const int32_t *rowptr, const int32_t *colidx, const double *val,
+                                         const double *Bt, int64_t ldbt, int64_t n, double alpha,
+                                         double beta, double *C, int64_t ldc)
+{
+    if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val) || n < 0) return SBLAS_E_INVALID;
+    if (rows == 0 || n == 0) return SBLAS_OK;
+    if (!C || ldc < rows || n > INT_MAX) return SBLAS_E_INVALID;
+    if (ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
+    if (cols > 0 && !Bt) return SBLAS_E_INVALID;
+    // the kernels address Bt with 32-bit element offsets (row * ldbt + column)
+    if ((uint64_t)cols * (uint64_t)ldbt > 0xffffffffull) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, rowptr, colidx, val, Bt, ldbt, (int)n,
+                                       alpha, beta, C, ldc) == hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, const double *val,
+                               const double *B, int64_t ldb, int64_t n, double alpha, double beta,
+                               double *C, int64_t ldc, void *workspace, size_t workspace_bytes)
+{
+    if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val) || n < 0) return SBLAS_E_INVALID;
+    if (rows == 0 || n == 0) return SBLAS_OK;
+    if (!C || ldc < rows) return SBLAS_E_INVALID;
+    if (cols > 0 && (!B || ldb < cols)) return SBLAS_E_INVALID;
+    const size_t need = sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
+    const int64_t ldbt = sblas_hip_spmm_ldbt(n);
+    double *Bt = static_cast<double *>(workspace);
+    int rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, n, B, ldb, Bt, ldbt);
+    if (rc != SBLAS_OK) return rc;
+    return sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n,
+                                                alpha, beta, C, ldc);
+}
+
+int sblas_hip_spmv_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, const double *val,
+                               const double *x, double alpha, double beta, double *y)
+{
+    if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val)) return SBLAS_E_INVALID;
+    if (rows == 0) return SBLAS_OK;
+    if (!y || (cols > 0 && !x)) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_spmv((hipStream_t)stream, (int)rows, nnz, rowptr, colidx, val, x, alpha, beta, y) ==
+                   hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+int sblas_hip_axpby_f64(int dev, void *stream, int64_t n, double alpha, const double *x, double beta,
+                        double *y)
+{
+    if (n < 0) return SBLAS_E_INVALID;
+    if (n == 0) return SBLAS_OK;
+    if (!x || !y) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_axpby((hipStream_t)stream, n, alpha, x, beta, y) == hipSuccess ? SBLAS_OK
+                                                                                       : SBLAS_E_HIP;
+}
+
+} // extern "C"

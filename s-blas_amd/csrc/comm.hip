@@ -1,0 +1,167 @@
+// comm.hip -- partial-result merge across the GPUs driven by one process.
+// RCCL (AMD's NCCL) is dlopen'ed on first use: libsblas_hip.so itself has no link-time dependency
+// on it, so the library also loads inside a Python process whose torch wheel ships its own RCCL
+// (there the Python side owns the communicator and calls torch.distributed instead).
+// Replaces spmm.h:179-181,189,260-262,279 and spmv.h:43-45,58,115-118,134.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+#include "../../include/sblas_hip.h"
+#include "kernels.h"
+
+namespace {
+
+// Minimal declarations of the RCCL entry points used (rccl.h:236, :260, :611, :919ff).
+typedef void *rcclComm_t;
+typedef int (*fn_CommInitAll)(rcclComm_t *, int, const int *);
+typedef int (*fn_CommDestroy)(rcclComm_t);
+typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t);
+typedef int (*fn_Group)(void);
+constexpr int RCCL_FLOAT64 = 8; // ncclFloat64 / ncclDouble, rccl.h:467
+constexpr int RCCL_SUM = 0;     // ncclSum, rccl.h:448
+
+struct Rccl {
+    void *handle = nullptr;
+    fn_CommInitAll CommInitAll = nullptr;
+    fn_CommDestroy CommDestroy = nullptr;
+    fn_AllReduce AllReduce = nullptr;
+    fn_Group GroupStart = nullptr, GroupEnd = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) return;
+        r.CommInitAll = (fn_CommInitAll)dlsym(r.handle, "ncclCommInitAll");
+        r.CommDestroy = (fn_CommDestroy)dlsym(r.handle, "ncclCommDestroy");
+        r.AllReduce = (fn_AllReduce)dlsym(r.handle, "ncclAllReduce");
+        r.GroupStart = (fn_Group)dlsym(r.handle, "ncclGroupStart");
+        r.GroupEnd = (fn_Group)dlsym(r.handle, "ncclGroupEnd");
+        r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd;
+    });
+    return r;
+}
+
+struct CommSet {
+    std::vector<int> devs;
+    bool one_device = false;         // every rank sits on the same physical device
+    std::vector<rcclComm_t> comms;   // empty when one_device or a single rank
+    std::vector<hipEvent_t> events;  // per rank, for the one-device path
+};
+
+std::mutex g_mu;
+std::map<std::vector<int>, std::unique_ptr<CommSet>> g_sets;
+
+} // namespace
+
+extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
+{
+    if (n_gpu <= 0 || n_gpu > sblas::MAX_REPLICAS || !comm_out) return SBLAS_E_INVALID;
+    std::vector<int> key(n_gpu);
+    for (int i = 0; i < n_gpu; ++i) key[i] = devs ? devs[i] : i;
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_sets.find(key);
+    if (it != g_sets.end()) {
+        *comm_out = it->second.get();
+        return SBLAS_OK;
+    }
+    auto set = std::make_unique<CommSet>();
+    set->devs = key;
+    bool all_same = true, all_distinct = true;
+    for (int i = 0; i < n_gpu; ++i)
+        for (int j = i + 1; j < n_gpu; ++j) {
+            if (key[i] != key[j]) all_same = false;
+            else all_distinct = false;
+        }
+    if (n_gpu == 1) {
+        // a single rank: the sum over ranks is the identity, no communicator needed
+    } else if (all_same) {
+        set->one_device = true;
+        int prev = 0;
+        (void)hipGetDevice(&prev);
+        if (hipSetDevice(key[0]) != hipSuccess) return SBLAS_E_HIP;
+        set->events.resize(n_gpu);
+        for (int i = 0; i < n_gpu; ++i)
+            if (hipEventCreateWithFlags(&set->events[i], hipEventDisableTiming) != hipSuccess) return SBLAS_E_HIP;
+        (void)hipSetDevice(prev);
+    } else if (all_distinct) {
+        Rccl &r = rccl();
+        if (!r.ok) return SBLAS_E_RCCL;
+        set->comms.resize(n_gpu);
+        if (r.CommInitAll(set->comms.data(), n_gpu, key.data()) != 0) return SBLAS_E_RCCL;
+    } else {
+        return SBLAS_E_INVALID; // partially oversubscribed layouts are not supported
+    }
+    *comm_out = set.get();
+    g_sets.emplace(key, std::move(set));
+    return SBLAS_OK;
+}
+
+extern "C" void sblas_hip_comm_release_all(void)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (auto &kv : g_sets) {
+        CommSet &s = *kv.second;
+        for (auto c : s.comms) rccl().CommDestroy(c);
+        for (auto e : s.events) (void)hipEventDestroy(e);
+    }
+    g_sets.clear();
+}
+
+extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void *const *streams, int64_t count)
+{
+    if (!comm || !bufs || count < 0) return SBLAS_E_INVALID;
+    if (count == 0) return SBLAS_OK;
+    CommSet &s = *static_cast<CommSet *>(comm);
+    const int g = (int)s.devs.size();
+    for (int i = 0; i < g; ++i)
+        if (!bufs[i]) return SBLAS_E_INVALID;
+    if (g == 1) return SBLAS_OK;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = SBLAS_OK;
+    if (s.one_device) {
+        // all ranks share a device: order rank 0's stream after every rank's producers, sum there,
+        // then order every other stream after the sum.
+        if (hipSetDevice(s.devs[0]) != hipSuccess) return SBLAS_E_HIP;
+        hipStream_t s0 = streams ? (hipStream_t)streams[0] : nullptr;
+        sblas::ReplicaPtrs p{};
+        for (int i = 0; i < g; ++i) p.p[i] = bufs[i];
+        for (int i = 1; i < g && rc == SBLAS_OK; ++i) {
+            hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
+            if (si == s0) continue;
+            if (hipEventRecord(s.events[i], si) != hipSuccess || hipStreamWaitEvent(s0, s.events[i], 0) != hipSuccess)
+                rc = SBLAS_E_HIP;
+        }
+        if (rc == SBLAS_OK && sblas::launch_sum_replicas(s0, p, g, count) != hipSuccess) rc = SBLAS_E_HIP;
+        if (rc == SBLAS_OK && hipEventRecord(s.events[0], s0) != hipSuccess) rc = SBLAS_E_HIP;
+        for (int i = 1; i < g && rc == SBLAS_OK; ++i) {
+            hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
+            if (si == s0) continue;
+            if (hipStreamWaitEvent(si, s.events[0], 0) != hipSuccess) rc = SBLAS_E_HIP;
+        }
+    } else {
+        Rccl &r = rccl();
+        if (!r.ok) return SBLAS_E_RCCL;
+        if (r.GroupStart() != 0) return SBLAS_E_RCCL;
+        for (int i = 0; i < g; ++i) {
+            if (hipSetDevice(s.devs[i]) != hipSuccess) { rc = SBLAS_E_HIP; break; }
+            if (r.AllReduce(bufs[i], bufs[i], (size_t)count, RCCL_FLOAT64, RCCL_SUM, s.comms[i],
+                            streams ? (hipStream_t)streams[i] : nullptr) != 0) { rc = SBLAS_E_RCCL; break; }
+        }
+        if (r.GroupEnd() != 0 && rc == SBLAS_OK) rc = SBLAS_E_RCCL;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}

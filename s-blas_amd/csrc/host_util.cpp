@@ -1,0 +1,296 @@
+// host_util.cpp -- host-side pure functions of the C ABI: placement arithmetic and the
+// MatrixMarket -> CSR loader.  No GPU call in this file; everything is testable on a CPU box.
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+#include "../../include/sblas_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// placement
+// ------------------------------------------------------------------------------------------
+extern "C" int32_t sblas_find_row_of_nnz(const int32_t *rowptr, int32_t rows, int32_t nnz_idx)
+{
+    // The reference scans linearly for the first r with rowptr[r] <= idx < rowptr[r+1]
+    // (utility.h:292-300).  rowptr is non-decreasing, so that r is the predecessor of the first
+    // entry strictly greater than idx.
+    if (!rowptr || rows <= 0 || nnz_idx < rowptr[0] || nnz_idx >= rowptr[rows]) return -1;
+    const int32_t *hi = std::upper_bound(rowptr, rowptr + rows + 1, nnz_idx);
+    return (int32_t)(hi - rowptr) - 1;
+}
+
+extern "C" int64_t sblas_partition_nnz(const int32_t *rowptr, int32_t rows, int32_t nnz, int n_gpu, int i_gpu,
+                                       int32_t *start_row, int32_t *stop_row, int32_t *nnz_i,
+                                       int64_t *first_nnz, int32_t *rebased_rowptr)
+{
+    if (!rowptr || rows <= 0 || nnz <= 0 || n_gpu <= 0 || i_gpu < 0 || i_gpu >= n_gpu) return -1;
+    // matrix.h:360 computes ceil((float)nnz / n_gpu); float loses integers above 2^24, so the
+    // product uses the exact quotient (identical below 2^24, see DESIGN.md "hazards").
+    const int64_t avg = ((int64_t)nnz + n_gpu - 1) / n_gpu;
+    const int64_t lo = (int64_t)i_gpu * avg;
+    const int64_t hi = std::min<int64_t>((int64_t)(i_gpu + 1) * avg, nnz); // one past the last
+    if (lo >= hi) return -2; // this rank owns nothing (g larger than the matrix can feed)
+    const int32_t s = sblas_find_row_of_nnz(rowptr, rows, (int32_t)lo);
+    const int32_t e = sblas_find_row_of_nnz(rowptr, rows, (int32_t)(hi - 1));
+    if (s < 0 || e < 0) return -3;
+    if (start_row) *start_row = s;
+    if (stop_row) *stop_row = e;
+    if (nnz_i) *nnz_i = (int32_t)(hi - lo);
+    if (first_nnz) *first_nnz = lo;
+    const int64_t num = (int64_t)e - s + 2; // get_gpu_row_ptr_num, matrix.h:398-404
+    if (rebased_rowptr) {
+        // matrix.h:370-375: first pointer 0, interior pointers shifted by the block's first
+        // nonzero, last pointer = the block's nonzero count (a row cut by the boundary is split).
+        rebased_rowptr[0] = 0;
+        for (int64_t k = 1; k < num - 1; ++k) rebased_rowptr[k] = (int32_t)(rowptr[s + k] - lo);
+        rebased_rowptr[num - 1] = (int32_t)(hi - lo);
+    }
+    return num;
+}
+
+extern "C" int sblas_partition_dense(int64_t first_order, int n_gpu, int i_gpu, int64_t *offset, int64_t *dim)
+{
+    if (first_order < 0 || n_gpu <= 0 || i_gpu < 0 || i_gpu >= n_gpu || !offset || !dim) return SBLAS_E_INVALID;
+    const int64_t avg = (first_order + n_gpu - 1) / n_gpu; // == ceil((double)first/g), matrix.h:559
+    const int64_t lo = (int64_t)i_gpu * avg;
+    const int64_t hi = std::min<int64_t>(lo + avg, first_order);
+    // the reference lets dim go negative when g*avg - avg > first (e.g. 9 columns on 8 GPUs);
+    // here such a rank simply owns an empty block.
+    *offset = std::min<int64_t>(lo, first_order);
+    *dim = hi > lo ? hi - lo : 0;
+    return SBLAS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// MatrixMarket loader: one read of the file, hand-rolled tokenizer, then the same
+// count -> exclusive scan -> scatter-in-file-order construction as mmio_highlevel.h:130-281.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct Parsed {
+    std::string path;
+    long long mtime_ns = 0;
+    long long size = -1;
+    int32_t rows = 0, cols = 0, nnz = 0, mirrored = 0;
+    std::vector<int32_t> rowptr, colidx;
+    std::vector<double> val;
+};
+
+std::mutex g_cache_mu;
+Parsed g_cache; // last file parsed: sblas_mm_read_info + sblas_mm_read_csr share one parse
+
+enum Field { F_REAL, F_COMPLEX, F_INTEGER, F_PATTERN };
+
+inline const char *skip_ws(const char *p, const char *end)
+{
+    while (p < end && isspace((unsigned char)*p)) ++p;
+    return p;
+}
+inline const char *token_end(const char *p, const char *end)
+{
+    while (p < end && !isspace((unsigned char)*p)) ++p;
+    return p;
+}
+inline std::string lowered(const char *b, const char *e)
+{
+    std::string s(b, e);
+    for (auto &ch : s) ch = (char)tolower((unsigned char)ch);
+    return s;
+}
+// "%d"-like: optional sign + digits; false when no digits were consumed
+inline bool parse_int(const char *&p, const char *end, long &out)
+{
+    p = skip_ws(p, end);
+    const char *q = p;
+    bool neg = false;
+    if (q < end && (*q == '-' || *q == '+')) neg = (*q++ == '-');
+    if (q >= end || !isdigit((unsigned char)*q)) return false;
+    long v = 0;
+    while (q < end && isdigit((unsigned char)*q)) v = v * 10 + (*q++ - '0');
+    out = neg ? -v : v;
+    p = q;
+    return true;
+}
+// "%lg": glibc's scanf hands the token to the same conversion as strtod
+inline bool parse_real(const char *&p, const char *end, double &out)
+{
+    p = skip_ws(p, end);
+    if (p >= end) return false;
+    char *stop = nullptr;
+    out = strtod(p, &stop); // buffer is NUL-terminated by the caller
+    if (stop == p) return false;
+    p = stop;
+    return true;
+}
+
+int parse_file(const char *path, Parsed &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return SBLAS_E_IO;
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) { fclose(f); return SBLAS_E_IO; }
+    std::vector<char> buf((size_t)st.st_size + 1);
+    const size_t got = fread(buf.data(), 1, (size_t)st.st_size, f);
+    fclose(f);
+    buf[got] = '\0';
+    const char *p = buf.data(), *end = buf.data() + got;
+
+    // banner (mmio.h:254-337): five tokens on the first line, the last four case-insensitive
+    const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+    const char *line_end = eol ? eol : end;
+    std::string tok[5];
+    {
+        const char *q = p;
+        for (int i = 0; i < 5; ++i) {
+            q = skip_ws(q, line_end);
+            const char *e = token_end(q, line_end);
+            if (e == q) return SBLAS_E_IO;
+            tok[i] = (i == 0) ? std::string(q, e) : lowered(q, e);
+            q = e;
+        }
+    }
+    if (tok[0].compare(0, 14, "%%MatrixMarket") != 0) return SBLAS_E_IO;
+    if (tok[1] != "matrix") return SBLAS_E_IO;
+    if (tok[2] != "coordinate" && tok[2] != "array") return SBLAS_E_IO;
+    Field field;
+    if (tok[3] == "real") field = F_REAL;
+    else if (tok[3] == "complex") field = F_COMPLEX;
+    else if (tok[3] == "pattern") field = F_PATTERN;
+    else if (tok[3] == "integer") field = F_INTEGER;
+    else return SBLAS_E_IO;
+    bool mirrored;
+    if (tok[4] == "general" || tok[4] == "skew-symmetric") mirrored = false; // skew is NOT mirrored (:46-51)
+    else if (tok[4] == "symmetric" || tok[4] == "hermitian") mirrored = true;
+    else return SBLAS_E_IO;
+    p = eol ? eol + 1 : end;
+
+    // size line (mmio.h:339-367): skip '%' lines; first other line; else keep scanning ints
+    long M = 0, N = 0, NZ = 0;
+    for (;;) {
+        if (p >= end) return SBLAS_E_IO;
+        eol = (const char *)memchr(p, '\n', (size_t)(end - p));
+        line_end = eol ? eol : end;
+        const bool comment = (*p == '%');
+        const char *q = p;
+        p = eol ? eol + 1 : end;
+        if (comment) continue;
+        const char *t = q;
+        if (parse_int(t, line_end, M) && parse_int(t, line_end, N) && parse_int(t, line_end, NZ)) break;
+        // blank / odd line: the reference falls back to fscanf("%d %d %d") on the stream
+        if (!(parse_int(p, end, M) && parse_int(p, end, N) && parse_int(p, end, NZ))) return SBLAS_E_IO;
+        break;
+    }
+    if (M < 0 || N < 0 || NZ < 0 || M > 0x7ffffffe || N > 0x7fffffff || NZ > 0x7fffffff) return SBLAS_E_IO;
+
+    std::vector<int32_t> ri((size_t)NZ), ci((size_t)NZ);
+    std::vector<double> v((size_t)NZ);
+    std::vector<int32_t> rowptr((size_t)M + 1, 0);
+    for (long e = 0; e < NZ; ++e) {
+        long i = 0, j = 0;
+        double re = 1.0;
+        if (!parse_int(p, end, i) || !parse_int(p, end, j)) return SBLAS_E_IO;
+        if (field == F_REAL) {
+            if (!parse_real(p, end, re)) return SBLAS_E_IO;
+        } else if (field == F_COMPLEX) {
+            double im;
+            if (!parse_real(p, end, re) || !parse_real(p, end, im)) return SBLAS_E_IO; // imaginary part dropped
+        } else if (field == F_INTEGER) {
+            long iv;
+            if (!parse_int(p, end, iv)) return SBLAS_E_IO;
+            re = (double)(int)iv;
+        }
+        if (i < 1 || i > M || j < 1 || j > N) return SBLAS_E_IO; // the reference would write out of bounds
+        if (mirrored && i != j && (j > M || i > N)) return SBLAS_E_IO;
+        ri[(size_t)e] = (int32_t)(i - 1);
+        ci[(size_t)e] = (int32_t)(j - 1);
+        v[(size_t)e] = re;
+        rowptr[(size_t)(i - 1)]++;
+    }
+    if (mirrored)
+        for (long e = 0; e < NZ; ++e)
+            if (ri[(size_t)e] != ci[(size_t)e]) rowptr[(size_t)ci[(size_t)e]]++;
+    // exclusive scan
+    long long run = 0;
+    for (long r = 0; r <= M; ++r) {
+        const long long here = rowptr[(size_t)r];
+        if (run > 0x7fffffffLL) return SBLAS_E_IO;
+        rowptr[(size_t)r] = (int32_t)run;
+        run += here;
+    }
+    const int32_t nnz = rowptr[(size_t)M];
+    out.colidx.assign((size_t)nnz, 0);
+    out.val.assign((size_t)nnz, 0.0);
+    std::vector<int32_t> cursor(rowptr.begin(), rowptr.end() - 1);
+    for (long e = 0; e < NZ; ++e) {
+        const int32_t i = ri[(size_t)e], j = ci[(size_t)e];
+        int32_t at = cursor[(size_t)i]++;
+        out.colidx[(size_t)at] = j;
+        out.val[(size_t)at] = v[(size_t)e];
+        if (mirrored && i != j) { // the (j,i) twin follows its original immediately (:242-262)
+            at = cursor[(size_t)j]++;
+            out.colidx[(size_t)at] = i;
+            out.val[(size_t)at] = v[(size_t)e];
+        }
+    }
+    out.rowptr.swap(rowptr);
+    out.rows = (int32_t)M;
+    out.cols = (int32_t)N;
+    out.nnz = nnz;
+    out.mirrored = mirrored ? 1 : 0;
+    out.path = path;
+    out.size = (long long)st.st_size;
+    out.mtime_ns = (long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    return SBLAS_OK;
+}
+
+// returns with g_cache_mu held by the caller
+int ensure_parsed(const char *path)
+{
+    struct stat st;
+    if (!path || stat(path, &st) != 0) return SBLAS_E_IO;
+    const long long mt = (long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
+    if (g_cache.size == (long long)st.st_size && g_cache.mtime_ns == mt && g_cache.path == path) return SBLAS_OK;
+    Parsed fresh;
+    const int rc = parse_file(path, fresh);
+    if (rc != SBLAS_OK) return rc;
+    g_cache = std::move(fresh);
+    return SBLAS_OK;
+}
+
+} // namespace
+
+extern "C" int sblas_mm_read_info(const char *path, int32_t *rows, int32_t *cols, int32_t *nnz,
+                                  int32_t *is_symmetric)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    const int rc = ensure_parsed(path);
+    if (rc != SBLAS_OK) return rc;
+    if (rows) *rows = g_cache.rows;
+    if (cols) *cols = g_cache.cols;
+    if (nnz) *nnz = g_cache.nnz;
+    if (is_symmetric) *is_symmetric = g_cache.mirrored;
+    return SBLAS_OK;
+}
+
+extern "C" int sblas_mm_read_csr(const char *path, int32_t *rowptr, int32_t *colidx, double *val)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    const int rc = ensure_parsed(path);
+    if (rc != SBLAS_OK) return rc;
+    if (!rowptr) return SBLAS_E_INVALID;
+    memcpy(rowptr, g_cache.rowptr.data(), g_cache.rowptr.size() * sizeof(int32_t));
+    if (g_cache.nnz > 0) {
+        if (!colidx || !val) return SBLAS_E_INVALID;
+        memcpy(colidx, g_cache.colidx.data(), (size_t)g_cache.nnz * sizeof(int32_t));
+        memcpy(val, g_cache.val.data(), (size_t)g_cache.nnz * sizeof(double));
+    }
+    // the parse is handed over once; drop it so a large matrix is not held twice
+    g_cache = Parsed();
+    return SBLAS_OK;
+}

@@ -1,0 +1,338 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the S-BLAS CSR hot path.
+//
+//   dense_to_rowmajor_kernel   B (col-major) -> Bt (row-major, zero padded)          [stage 1 of SpMM]
+//   spmm_rowpanel_kernel       C = alpha*A*Bt + beta*C, one 32-row panel per workgroup [stage 2]
+//   spmm_rowpanel_narrow_kernel  same for n <= 32 (sub-wave lane groups)
+//   spmv_csr_kernel            y = alpha*A*x + beta*y, LPR lanes per row + in-wave reduction
+//   axpby_kernel               y = beta*y + alpha*x
+//   sum_replicas_kernel        in-place sum over g buffers that live on ONE device
+//
+// These replace the closed-source cuSPARSE calls of the reference (spmm.h:146-149, :248-251;
+// spmv.h:104-106) and its one utility kernel (kernel.h:27-38).  Everything is written for
+// 64-wide wavefronts; there is no 32-lane code path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace sblas {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1: Bt[k][j] = B[k + j*ldb]   (k < cols, j < n), Bt[k][j] = 0 for n <= j < ldbt.
+// 64 x 64 tile through LDS: global reads run along k (contiguous in col-major B), global writes
+// run along j (contiguous in row-major Bt).  Row stride 65 doubles keeps both LDS phases
+// conflict-free for ds_read/write_b64 (lanes 0..31 land on distinct bank pairs).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, int64_t n,
+                                                               const double *__restrict__ B, int64_t ldb,
+                                                               double *__restrict__ Bt, int64_t ldbt)
+{
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t k0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+#pragma unroll 4
+    for (int jj = ty; jj < 64; jj += 4) {
+        const int64_t j = j0 + jj, k = k0 + tx;
+        double v = 0.0;
+        if (j < n && k < cols) v = B[k + j * ldb];
+        tile[jj][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = ty; kk < 64; kk += 4) {
+        const int64_t k = k0 + kk, j = j0 + tx;
+        if (k < cols && j < ldbt) Bt[k * ldbt + j] = tile[tx][kk];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, wide form (ldbt a multiple of 64).
+// Workgroup = 4 waves = one panel of PANEL_ROWS consecutive rows x one 64-column tile of C.
+// A wave owns whole rows; its 64 lanes are the 64 columns of the tile, so
+//   - row_ptr / col_idx / val of a row are read once per wave, 64 nonzeros per coalesced load
+//     (lane l takes nonzero p+l), and handed to all lanes through v_readlane (the column index and
+//     the value become scalars -> the B address is scalar base + lane*8, one full 512-byte row of
+//     Bt per nonzero, perfectly coalesced);
+//   - the accumulator is one fp64 register per lane, summed in CSR order (same order as the
+//     reference's CPU loop, spmm.h:59-64);
+//   - finished rows are parked in an LDS tile [column][row] and the panel is written back with
+//     lanes running along the row index, which is the contiguous direction of column-major C
+//     (this is also where alpha/beta are applied, so C is read and written exactly once).
+// ---------------------------------------------------------------------------------------------
+constexpr int PANEL_ROWS = 32;
+constexpr int ROWS_PER_WAVE = PANEL_ROWS / 4;
+
+__global__ __launch_bounds__(256) void spmm_rowpanel_kernel(int rows, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ Bt, int64_t ldbt, int n,
+                                                           double alpha, double beta, double *__restrict__ C,
+                                                           int64_t ldc)
+{
+    __shared__ double ctile[64][PANEL_ROWS + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    const int row0 = blockIdx.x * PANEL_ROWS;
+    const int col0 = blockIdx.y * 64;
+    // Row c of Bt starts at element c*ldbt: a 32-bit scalar product (cols*ldbt < 2^32 is checked by the
+    // C ABI), so the load is "scalar row base + one constant per-lane offset" with no vector address math.
+    const unsigned lane_off = (unsigned)(col0 + lane);
+    const unsigned ld32 = (unsigned)ldbt;
+
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const int r = wave * ROWS_PER_WAVE + rr;
+        const int row = row0 + r;
+        double acc = 0.0;
+        if (row < rows) {
+            const int p0 = wave_uniform(rowptr[row]);
+            const int p1 = wave_uniform(rowptr[row + 1]);
+            for (int p = p0; p < p1; p += WAVE) {
+                const int mine = p + lane;
+                int cj = 0;
+                double vj = 0.0;
+                if (mine < p1) {
+                    cj = colidx[mine];
+                    vj = val[mine];
+                }
+                const int cnt = min(WAVE, p1 - p);
+                int k = 0;
+                for (; k + 8 <= cnt; k += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = __builtin_amdgcn_readlane(cj, k + u);
+                        const double a = readlane_f64(vj, k + u);
+                        acc = fma(a, (Bt + (size_t)((unsigned)c * ld32))[lane_off], acc);
+                    }
+                }
+                for (; k < cnt; ++k) {
+                    const int c = __builtin_amdgcn_readlane(cj, k);
+                    const double a = readlane_f64(vj, k);
+                    acc = fma(a, (Bt + (size_t)((unsigned)c * ld32))[lane_off], acc);
+                }
+            }
+        }
+        ctile[lane][r] = acc;
+    }
+    __syncthreads();
+
+    // write-back: consecutive threads walk consecutive rows of one column of C
+    const int nrows = min(PANEL_ROWS, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = threadIdx.x; idx < 64 * PANEL_ROWS; idx += 256) {
+        const int r = idx % PANEL_ROWS, j = idx / PANEL_ROWS;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double s = alpha * ctile[j][r];
+            *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, narrow form (ldbt = G in {8,16,32}, n <= G): a group of G lanes owns a row, so a wave
+// works on 64/G rows at once and every lane fetches its row's (col, val) itself (the G lanes of a
+// group read the same address, which the memory pipeline serves as one request).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, const int *__restrict__ rowptr,
+                                                                  const int *__restrict__ colidx,
+                                                                  const double *__restrict__ val,
+                                                                  const double *__restrict__ Bt, int n,
+                                                                  double alpha, double beta,
+                                                                  double *__restrict__ C, int64_t ldc)
+{
+    constexpr int GROUPS = 256 / G;
+    constexpr int RPG = PANEL_ROWS / GROUPS; // rows per group
+    static_assert(RPG >= 1, "panel too small for this group width");
+    __shared__ double ctile[G][PANEL_ROWS + 1];
+    const int l = threadIdx.x % G, grp = threadIdx.x / G;
+    const int row0 = blockIdx.x * PANEL_ROWS;
+    for (int rr = 0; rr < RPG; ++rr) {
+        const int r = grp * RPG + rr;
+        const int row = row0 + r;
+        double acc = 0.0;
+        if (row < rows) {
+            const int p0 = rowptr[row], p1 = rowptr[row + 1];
+            int p = p0;
+            for (; p + 4 <= p1; p += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc = fma(val[p + u], Bt[(int64_t)colidx[p + u] * G + l], acc);
+            }
+            for (; p < p1; ++p) acc = fma(val[p], Bt[(int64_t)colidx[p] * G + l], acc);
+        }
+        ctile[l][r] = acc;
+    }
+    __syncthreads();
+    const int nrows = min(PANEL_ROWS, rows - row0);
+    for (int idx = threadIdx.x; idx < G * PANEL_ROWS; idx += 256) {
+        const int r = idx % PANEL_ROWS, j = idx / PANEL_ROWS;
+        if (r < nrows && j < n) {
+            double *dst = C + (int64_t)j * ldc + (row0 + r);
+            const double s = alpha * ctile[j][r];
+            *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV: LPR lanes per row (a power of two, 4..64), 256/LPR rows per workgroup.  The lanes of a
+// group stride through the row's nonzeros (coalesced col_idx / val streams, x gathered through
+// L2), then the partial sums are folded with xor-shuffles inside the wave -- the wave64 successor of
+// the reference's unused sum_32_shfl (utility.h:241-246).
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__restrict__ rowptr,
+                                                      const int *__restrict__ colidx,
+                                                      const double *__restrict__ val,
+                                                      const double *__restrict__ x, double alpha, double beta,
+                                                      double *__restrict__ y)
+{
+    constexpr int ROWS_PER_BLOCK = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / LPR;
+    double s0 = 0.0, s1 = 0.0;
+    if (row < rows) {
+        const int p1 = rowptr[row + 1];
+        int p = rowptr[row] + l;
+        for (; p + LPR < p1; p += 2 * LPR) {
+            const int c0 = colidx[p], c1 = colidx[p + LPR];
+            const double a0 = val[p], a1 = val[p + LPR];
+            s0 = fma(a0, x[c0], s0);
+            s1 = fma(a1, x[c1], s1);
+        }
+        if (p < p1) s0 = fma(val[p], x[colidx[p]], s0);
+    }
+    double s = s0 + s1;
+#pragma unroll
+    for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, WAVE);
+    if (row < rows && l == 0) {
+        const double r = alpha * s;
+        y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = beta*y + alpha*x  (kernel.h:27-38), two doubles per lane per step, grid-stride.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void axpby_kernel(int64_t n, double alpha, const double *__restrict__ x,
+                                                   double beta, double *__restrict__ y)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool aligned = ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    if (aligned) {
+        const int64_t n2 = n >> 1;
+        const double2 *x2 = reinterpret_cast<const double2 *>(x);
+        double2 *y2 = reinterpret_cast<double2 *>(y);
+        for (int64_t i = tid; i < n2; i += stride) {
+            double2 a = x2[i], b = y2[i];
+            b.x = b.x * beta + a.x * alpha;
+            b.y = b.y * beta + a.y * alpha;
+            y2[i] = b;
+        }
+        if ((n & 1) && tid == 0) y[n - 1] = y[n - 1] * beta + x[n - 1] * alpha;
+    } else {
+        for (int64_t i = tid; i < n; i += stride) y[i] = y[i] * beta + x[i] * alpha;
+    }
+}
+
+// In-place sum of g replicas that share a device: every buffer ends up holding the sum, added in
+// rank order (the single-device stand-in for the all-reduce when ranks are oversubscribed).
+__global__ __launch_bounds__(256) void sum_replicas_kernel(ReplicaPtrs bufs, int g, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double s = 0.0;
+        for (int q = 0; q < g; ++q) s += bufs.p[q][i];
+        for (int q = 0; q < g; ++q) bufs.p[q][i] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline unsigned capped_grid(int64_t work_items, int per_block)
+{
+    int64_t b = (work_items + per_block - 1) / per_block;
+    const int64_t cap = 256 * 8; // CUs x resident blocks (guide: cap memory-bound grids, stride the rest)
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
+                                    double *Bt, int64_t ldbt)
+{
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((ldbt + 63) / 64));
+    hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, const int *rowptr, const int *colidx,
+                                const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
+                                double beta, double *C, int64_t ldc)
+{
+    const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
+    if (ldbt >= 64) {
+        dim3 grid(panels, (unsigned)(ldbt / 64));
+        hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(256), 0, s, rows, rowptr, colidx, val, Bt, ldbt, n,
+                           alpha, beta, C, ldc);
+    } else if (ldbt == 32) {
+        hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<32>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
+                           val, Bt, n, alpha, beta, C, ldc);
+    } else if (ldbt == 16) {
+        hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<16>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
+                           val, Bt, n, alpha, beta, C, ldc);
+    } else {
+        hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<8>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
+                           val, Bt, n, alpha, beta, C, ldc);
+    }
+    return hipGetLastError();
+}
+
+template <int LPR>
+static hipError_t spmv_go(hipStream_t s, int rows, const int *rowptr, const int *colidx, const double *val,
+                          const double *x, double alpha, double beta, double *y)
+{
+    constexpr int rpb = 256 / LPR;
+    hipLaunchKernelGGL(spmv_csr_kernel<LPR>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, rows,
+                       rowptr, colidx, val, x, alpha, beta, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmv(hipStream_t s, int rows, int64_t nnz, const int *rowptr, const int *colidx,
+                       const double *val, const double *x, double alpha, double beta, double *y)
+{
+    const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    if (avg <= 6.0) return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 12.0) return spmv_go<8>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 24.0) return spmv_go<16>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 48.0) return spmv_go<32>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    return spmv_go<64>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+}
+
+hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y)
+{
+    hipLaunchKernelGGL(axpby_kernel, dim3(capped_grid(n, 512)), dim3(256), 0, s, n, alpha, x, beta, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_replicas(hipStream_t s, const ReplicaPtrs &bufs, int g, int64_t n)
+{
+    hipLaunchKernelGGL(sum_replicas_kernel, dim3(capped_grid(n, 256)), dim3(256), 0, s, bufs, g, n);
+    return hipGetLastError();
+}
+
+} // namespace sblas

@@ -1,0 +1,199 @@
+"""ctypes binding of libsblas_hip.so (the C ABI in include/sblas_hip.h).
+
+Plumbing only: torch supplies device memory and streams, every compute call goes through the
+shared library.  There is no CPU or torch fallback here -- if the HIP library is missing, or a
+tensor is not on the GPU, the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.normpath(os.path.join(_PKG, "..", ".."))
+LIB_PATH = os.path.join(_ROOT, "lib", "libsblas_hip.so")
+
+# every symbol include/sblas_hip.h declares (tests check that the .so exports all of them)
+EXPORTS = [
+    "sblas_hip_version", "sblas_hip_error_string", "sblas_hip_device_count",
+    "sblas_hip_spmm_csr_f64_i32_workspace", "sblas_hip_spmm_csr_f64_i32", "sblas_hip_spmm_ldbt",
+    "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
+    "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
+    "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
+    "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
+    "sblas_mm_read_info", "sblas_mm_read_csr",
+]
+
+
+class SblasError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SblasError("libsblas_hip.so not built (%s): run __graft_entry__.build() / make -C s-blas_amd" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i64, i32, f64, vp, sz = C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_size_t
+    L.sblas_hip_version.restype = C.c_int
+    L.sblas_hip_error_string.restype = C.c_char_p
+    L.sblas_hip_error_string.argtypes = [C.c_int]
+    L.sblas_hip_device_count.restype = C.c_int
+    L.sblas_hip_spmm_ldbt.restype = i64
+    L.sblas_hip_spmm_ldbt.argtypes = [i64]
+    L.sblas_hip_spmm_csr_f64_i32_workspace.restype = sz
+    L.sblas_hip_spmm_csr_f64_i32_workspace.argtypes = [i64, i64, i64, i64]
+    L.sblas_hip_spmm_csr_f64_i32.restype = C.c_int
+    L.sblas_hip_spmm_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64, vp, sz]
+    L.sblas_hip_dense_to_rowmajor_f64.restype = C.c_int
+    L.sblas_hip_dense_to_rowmajor_f64.argtypes = [C.c_int, vp, i64, i64, vp, i64, vp, i64]
+    L.sblas_hip_spmm_csr_rowmajorB_f64_i32.restype = C.c_int
+    L.sblas_hip_spmm_csr_rowmajorB_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64]
+    L.sblas_hip_spmv_csr_f64_i32.restype = C.c_int
+    L.sblas_hip_spmv_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, f64, f64, vp]
+    L.sblas_hip_axpby_f64.restype = C.c_int
+    L.sblas_hip_axpby_f64.argtypes = [C.c_int, vp, i64, f64, vp, f64, vp]
+    L.sblas_hip_comm_get.restype = C.c_int
+    L.sblas_hip_comm_get.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]
+    L.sblas_hip_comm_release_all.restype = None
+    L.sblas_hip_allreduce_sum_f64.restype = C.c_int
+    L.sblas_hip_allreduce_sum_f64.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64]
+    L.sblas_find_row_of_nnz.restype = i32
+    L.sblas_find_row_of_nnz.argtypes = [vp, i32, i32]
+    L.sblas_partition_nnz.restype = i64
+    L.sblas_partition_nnz.argtypes = [vp, i32, i32, C.c_int, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), vp]
+    L.sblas_partition_dense.restype = C.c_int
+    L.sblas_partition_dense.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.sblas_mm_read_info.restype = C.c_int
+    L.sblas_mm_read_info.argtypes = [C.c_char_p] + [C.POINTER(i32)] * 4
+    L.sblas_mm_read_csr.restype = C.c_int
+    L.sblas_mm_read_csr.argtypes = [C.c_char_p, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SblasError("%s failed: %s (code %d)" % (what, lib().sblas_hip_error_string(rc).decode(), rc))
+
+
+# ------------------------------------------------------------------------------------------
+# host-side pure functions
+# ------------------------------------------------------------------------------------------
+def read_mtx(path):
+    """MatrixMarket -> (rows, cols, nnz, symmetric, rowptr[int32], colidx[int32], val[float64])."""
+    L = lib()
+    r, c, z, s = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(L.sblas_mm_read_info(os.fsencode(path), C.byref(r), C.byref(c), C.byref(z), C.byref(s)), "sblas_mm_read_info")
+    rowptr = np.zeros(r.value + 1, np.int32)
+    colidx = np.zeros(max(z.value, 1), np.int32)
+    val = np.zeros(max(z.value, 1), np.float64)
+    check(L.sblas_mm_read_csr(os.fsencode(path), rowptr.ctypes.data, colidx.ctypes.data, val.ctypes.data), "sblas_mm_read_csr")
+    return r.value, c.value, z.value, s.value, rowptr, colidx[:z.value], val[:z.value]
+
+
+def find_row_of_nnz(rowptr, nnz_idx):
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    return int(lib().sblas_find_row_of_nnz(rowptr.ctypes.data, len(rowptr) - 1, int(nnz_idx)))
+
+
+def partition_nnz(rowptr, n_gpu, i_gpu):
+    """-> dict(start_row, stop_row, nnz, first_nnz, rowptr) of GPU i's nnz-balanced row block."""
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    rows = len(rowptr) - 1
+    nnz = int(rowptr[-1])
+    s, e, k, f = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    buf = np.zeros(rows + 2, np.int32)
+    num = lib().sblas_partition_nnz(rowptr.ctypes.data, rows, nnz, n_gpu, i_gpu, C.byref(s), C.byref(e),
+                                    C.byref(k), C.byref(f), buf.ctypes.data)
+    if num < 0:
+        raise SblasError("sblas_partition_nnz failed (%d)" % num)
+    return dict(start_row=s.value, stop_row=e.value, nnz=k.value, first_nnz=f.value, rowptr=buf[:num].copy())
+
+
+def partition_dense(first_order, n_gpu, i_gpu):
+    o, d = C.c_int64(), C.c_int64()
+    check(lib().sblas_partition_dense(first_order, n_gpu, i_gpu, C.byref(o), C.byref(d)), "sblas_partition_dense")
+    return o.value, d.value
+
+
+# ------------------------------------------------------------------------------------------
+# device calls (torch tensors carry the device pointers)
+# ------------------------------------------------------------------------------------------
+def _dev_ptr(t, dtype, what):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise SblasError("%s must be a GPU tensor (no CPU path exists)" % what)
+    if t.dtype != dtype or not t.is_contiguous():
+        raise SblasError("%s must be a contiguous %s tensor" % (what, dtype))
+    return t.data_ptr()
+
+
+def _stream(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def spmm_workspace_bytes(rows, cols, nnz, n):
+    return int(lib().sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n))
+
+
+def spmm(rows, cols, rowptr, colidx, val, B, ldb, n, alpha, beta, Cmat, ldc, workspace, stream=None, c_offset=0):
+    """C = alpha*A*B + beta*C through sblas_hip_spmm_csr_f64_i32.  B, C column-major flat tensors.
+    c_offset: element offset into Cmat (method 2 points C at Ccopy + start_row)."""
+    import torch
+    nnz = int(colidx.numel())
+    rc = lib().sblas_hip_spmm_csr_f64_i32(
+        -1, _stream(stream), rows, cols, nnz,
+        _dev_ptr(rowptr, torch.int32, "rowptr"), _dev_ptr(colidx, torch.int32, "colidx") if nnz else None,
+        _dev_ptr(val, torch.float64, "val") if nnz else None,
+        _dev_ptr(B, torch.float64, "B"), ldb, n, alpha, beta,
+        _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc,
+        _dev_ptr(workspace, torch.float64, "workspace"), workspace.numel() * 8)
+    check(rc, "sblas_hip_spmm_csr_f64_i32")
+
+
+def dense_to_rowmajor(cols, n, B, ldb, Bt, stream=None):
+    import torch
+    ldbt = int(lib().sblas_hip_spmm_ldbt(n))
+    check(lib().sblas_hip_dense_to_rowmajor_f64(-1, _stream(stream), cols, n, _dev_ptr(B, torch.float64, "B"), ldb,
+                                                _dev_ptr(Bt, torch.float64, "Bt"), ldbt), "sblas_hip_dense_to_rowmajor_f64")
+    return ldbt
+
+
+def spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, alpha, beta, Cmat, ldc, stream=None, c_offset=0):
+    import torch
+    nnz = int(colidx.numel())
+    ldbt = int(lib().sblas_hip_spmm_ldbt(n))
+    rc = lib().sblas_hip_spmm_csr_rowmajorB_f64_i32(
+        -1, _stream(stream), rows, cols, nnz,
+        _dev_ptr(rowptr, torch.int32, "rowptr"), _dev_ptr(colidx, torch.int32, "colidx") if nnz else None,
+        _dev_ptr(val, torch.float64, "val") if nnz else None,
+        _dev_ptr(Bt, torch.float64, "Bt"), ldbt, n, alpha, beta,
+        _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc)
+    check(rc, "sblas_hip_spmm_csr_rowmajorB_f64_i32")
+
+
+def spmv(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offset=0):
+    import torch
+    nnz = int(colidx.numel())
+    rc = lib().sblas_hip_spmv_csr_f64_i32(
+        -1, _stream(stream), rows, cols, nnz,
+        _dev_ptr(rowptr, torch.int32, "rowptr"), _dev_ptr(colidx, torch.int32, "colidx") if nnz else None,
+        _dev_ptr(val, torch.float64, "val") if nnz else None,
+        _dev_ptr(x, torch.float64, "x"), alpha, beta, _dev_ptr(y, torch.float64, "y") + 8 * y_offset)
+    check(rc, "sblas_hip_spmv_csr_f64_i32")
+
+
+def axpby(n, alpha, x, beta, y, stream=None):
+    """y = beta*y + alpha*x (kernel.h:27-38 semantics)."""
+    import torch
+    px, py = _dev_ptr(x, torch.float64, "x"), _dev_ptr(y, torch.float64, "y")
+    check(lib().sblas_hip_axpby_f64(-1, _stream(stream), n, alpha, px, beta, py), "sblas_hip_axpby_f64")

@@ -1,0 +1,326 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+Tolerance: fp64 within 1e-10 relative (north_star); indices/partition tables are integer-exact and are
+checked in the CPU suite.  Everything here is @pytest.mark.gpu and fails (not skips) without a device."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10          # north_star: "fp64 within 1e-10 rel"
+ATOL = 1e-12          # floor for results near zero (inputs are O(1), sums O(1e2))
+
+
+def close(got, ref):
+    return np.allclose(got, ref, rtol=RTOL, atol=ATOL)
+
+
+class Dev:
+    """A CSR matrix resident on the GPU (torch owns the memory; the C ABI gets raw pointers)."""
+
+    def __init__(self, torch, dev, rowptr, colidx, val, cols):
+        self.rows = len(rowptr) - 1
+        self.cols = cols
+        self.h = (np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32), np.ascontiguousarray(val, np.float64))
+        self.rowptr = torch.from_numpy(self.h[0]).to(dev)
+        self.colidx = torch.from_numpy(self.h[1]).to(dev)
+        self.val = torch.from_numpy(self.h[2]).to(dev)
+
+
+def gpu_spmm(sblas, torch, dev, A, B_host, ldb, n, alpha, beta, C_host, ldc):
+    B = torch.from_numpy(B_host).to(dev)
+    C = torch.from_numpy(C_host.copy()).to(dev)
+    ws = torch.empty(max(1, sblas.spmm_workspace_bytes(A.rows, A.cols, len(A.h[1]), n) // 8), dtype=torch.float64, device=dev)
+    sblas.spmm(A.rows, A.cols, A.rowptr, A.colidx, A.val, B, ldb, n, alpha, beta, C, ldc, ws)
+    torch.cuda.synchronize()
+    return C.cpu().numpy()
+
+
+def oracle_spmm_ld(oracle, A, B_host, ldb, n, alpha, beta, C_host, ldc):
+    """Oracle works on packed col-major arrays; pack/unpack the leading dimensions around it."""
+    rp, ci, v = A.h
+    Bp = np.ascontiguousarray(B_host.reshape(-1)[: ldb * n].reshape(n, ldb)[:, : A.cols]).reshape(-1) if A.cols else np.zeros(0)
+    Cfull = C_host.copy()
+    Cv = Cfull.reshape(-1)[: ldc * n].reshape(n, ldc)
+    Cp = np.ascontiguousarray(Cv[:, : A.rows]).reshape(-1)
+    oracle.spmm(A.rows, A.cols, n, rp, ci, v, Bp, Cp, alpha, beta)
+    Cv[:, : A.rows] = Cp.reshape(n, A.rows)
+    return Cfull
+
+
+@pytest.fixture(scope="module")
+def env(sblas, oracle, cuda):
+    import torch
+    assert sblas.lib().sblas_hip_device_count() >= 1
+    return sblas, oracle, torch, cuda
+
+
+def test_ash85_spmv_known_answers(env, ash85):
+    """BASELINE config 2: ash85 SpMV fp64 on 1 GPU vs the CPU verifier (x = y0 = 1)."""
+    sblas, oracle, torch, dev = env
+    with open(os.path.join(GOLDEN, "ash85_golden.json")) as f:
+        gold = json.load(f)
+    A = Dev(torch, dev, ash85["rowptr"], ash85["colidx"], ash85["val"], 85)
+    for key in ("spmv_a1_b1", "spmv_a3_b4"):
+        g = gold[key]
+        x = torch.ones(85, dtype=torch.float64, device=dev)
+        y = torch.ones(85, dtype=torch.float64, device=dev)
+        sblas.spmv(85, 85, A.rowptr, A.colidx, A.val, x, g["alpha"], g["beta"], y)
+        got = y.cpu().numpy()
+        ref = oracle.spmv(85, *A.h, np.ones(85), np.ones(85), g["alpha"], g["beta"])
+        assert close(got, ref)
+        assert (got[0], got[1], got[84], got.sum()) == (g["y_first"], g["y_second"], g["y_last"], g["y_sum"])  # small integers: exact
+
+
+@pytest.mark.parametrize("key", ["spmm_n64_a1_b1", "spmm_n256_a3_b4"])
+def test_ash85_spmm_known_answers(env, ash85, key):
+    """BASELINE config 1 inputs (and unit_test.cu:183's N=256, alpha=3, beta=4) on the GPU path."""
+    sblas, oracle, torch, dev = env
+    with open(os.path.join(GOLDEN, "ash85_golden.json")) as f:
+        g = json.load(f)[key]
+    N = g["N"]
+    A = Dev(torch, dev, ash85["rowptr"], ash85["colidx"], ash85["val"], 85)
+    B = oracle.rand0to1(85 * N)
+    C0 = np.full(85 * N, g["C0"])
+    got = gpu_spmm(sblas, torch, dev, A, B, 85, N, g["alpha"], g["beta"], C0, 85)
+    ref = oracle.spmm(85, 85, N, *A.h, B, C0.copy(), g["alpha"], g["beta"])
+    assert close(got, ref)
+    for idx, name in ((0, "C_first"), (1, "C_second"), (-1, "C_last")):
+        assert abs(got[idx] - g[name]) <= RTOL * abs(g[name])
+    assert abs(got.sum() - g["C_sum"]) <= 1e-9 * g["C_sum"]
+    assert oracle.lib().orc_check_equal(ref, got, got.size) == 1          # the reference's own criterion (1e-3 abs)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 130, 256])
+def test_spmm_every_column_count(env, n):
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rp, ci, v = synth.random_csr(150, 97, 9, seed=n, empty_every=11, long_row=(5, 333))
+    A = Dev(torch, dev, rp, ci, v, 97)
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal(97 * n)
+    C0 = rng.standard_normal(150 * n)
+    for alpha, beta in ((1.0, 1.0), (-2.5, 0.75), (1.0, 0.0)):
+        got = gpu_spmm(sblas, torch, dev, A, B, 97, n, alpha, beta, C0, 150)
+        ref = oracle.spmm(150, 97, n, *A.h, B, C0.copy(), alpha, beta)
+        assert close(got, ref), (n, alpha, beta, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("n", [8, 64, 96])
+def test_spmm_leading_dimensions_and_untouched_padding(env, n):
+    """ldb > K and ldc > M (method 2 writes into Ccopy with ldc = M != m_i, spmm.h:224-231): the rows of C
+    between M and ldc must not be touched."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    M, K, ldb, ldc = 77, 53, 60, 90
+    rp, ci, v = synth.random_csr(M, K, 6, seed=3)
+    A = Dev(torch, dev, rp, ci, v, K)
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal(ldb * n)
+    C0 = rng.standard_normal(ldc * n)
+    got = gpu_spmm(sblas, torch, dev, A, B, ldb, n, 1.5, -0.5, C0, ldc)
+    ref = oracle_spmm_ld(oracle, A, B, ldb, n, 1.5, -0.5, C0, ldc)
+    assert close(got, ref)
+    pad_got = got.reshape(n, ldc)[:, M:]
+    assert (pad_got == C0.reshape(n, ldc)[:, M:]).all()
+
+
+def test_spmm_beta_zero_does_not_read_c(env):
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rp, ci, v = synth.random_csr(40, 40, 5, seed=9)
+    A = Dev(torch, dev, rp, ci, v, 40)
+    B = np.random.default_rng(1).standard_normal(40 * 64)
+    C0 = np.full(40 * 64, np.nan)
+    got = gpu_spmm(sblas, torch, dev, A, B, 40, 64, 2.0, 0.0, C0, 40)
+    ref = oracle.spmm(40, 40, 64, *A.h, B, np.zeros(40 * 64), 2.0, 0.0)
+    assert np.isfinite(got).all() and close(got, ref)
+
+
+def test_spmm_degenerate_shapes(env):
+    sblas, oracle, torch, dev = env
+    # nnz = 0: C = beta*C
+    rp = np.zeros(11, np.int32)
+    A = Dev(torch, dev, rp, np.zeros(0, np.int32), np.zeros(0), 6)
+    C0 = np.arange(10 * 64, dtype=np.float64)
+    got = gpu_spmm(sblas, torch, dev, A, np.ones(6 * 64), 6, 64, 1.0, 3.0, C0, 10)
+    assert (got == 3.0 * C0).all()
+    # one row, one column, one nonzero
+    A = Dev(torch, dev, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.0]), 1)
+    got = gpu_spmm(sblas, torch, dev, A, np.array([4.0]), 1, 1, 1.0, 1.0, np.array([1.0]), 1)
+    assert got.tolist() == [9.0]
+    # a single row much longer than a wavefront, duplicates included
+    K = 1000
+    ci = (np.arange(5000) * 7 % K).astype(np.int32)
+    v = np.random.default_rng(2).standard_normal(5000)
+    A = Dev(torch, dev, np.array([0, 5000], np.int32), ci, v, K)
+    B = np.random.default_rng(3).standard_normal(K * 64)
+    got = gpu_spmm(sblas, torch, dev, A, B, K, 64, 1.0, 0.0, np.zeros(64), 1)
+    ref = oracle.spmm(1, K, 64, *A.h, B, np.zeros(64), 1.0, 0.0)
+    assert close(got, ref)
+
+
+def test_spmm_rows_not_multiple_of_panel_and_rectangular(env):
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    for (M, K) in ((1, 300), (31, 5), (33, 64), (257, 129), (1000, 10)):
+        rp, ci, v = synth.random_csr(M, K, 12, seed=M)
+        A = Dev(torch, dev, rp, ci, v, K)
+        rng = np.random.default_rng(M)
+        B, C0 = rng.standard_normal(K * 64), rng.standard_normal(M * 64)
+        got = gpu_spmm(sblas, torch, dev, A, B, K, 64, 1.0, 1.0, C0, M)
+        assert close(got, oracle.spmm(M, K, 64, *A.h, B, C0.copy(), 1.0, 1.0)), (M, K)
+
+
+def test_spmm_nd24k_like_reduced(env):
+    """The bench workload's structure (399 nnz/row, band +-2000) at 3 % of its rows, vs the oracle."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, (rp, ci, v) = synth.nd24k_like(scale=0.03)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(7)
+    B, C0 = rng.random(rows * 64), np.ones(rows * 64)
+    got = gpu_spmm(sblas, torch, dev, A, B, rows, 64, 1.0, 1.0, C0, rows)
+    ref = oracle.spmm(rows, rows, 64, *A.h, B, C0.copy(), 1.0, 1.0)
+    assert close(got, ref)
+
+
+@pytest.mark.parametrize("g", [1, 2, 4, 8])
+def test_method1_column_blocks(env, ash85, g):
+    """Method 1 (spmm.h:83-161): GPU i owns columns [i*ceil(N/g), ...) of B and C with the full A; the blocks
+    together must equal the verifier.  (All blocks run on this one GPU; placement is host arithmetic.)"""
+    sblas, oracle, torch, dev = env
+    N = 64
+    A = Dev(torch, dev, ash85["rowptr"], ash85["colidx"], ash85["val"], 85)
+    B = oracle.rand0to1(85 * N)
+    C = np.ones(85 * N)
+    for i in range(g):
+        off, dim = sblas.partition_dense(N, g, i)
+        blk = gpu_spmm(sblas, torch, dev, A, B[off * 85:(off + dim) * 85].copy(), 85, dim, 3.0, 4.0, C[off * 85:(off + dim) * 85].copy(), 85)
+        C[off * 85:(off + dim) * 85] = blk
+    ref = oracle.spmm(85, 85, N, *A.h, B, np.ones(85 * N), 3.0, 4.0)
+    assert close(C, ref)
+
+
+@pytest.mark.parametrize("g", [1, 2, 4, 8])
+def test_method2_row_blocks_merge_and_epilogue(env, ash85, g):
+    """Method 2 (spmm.h:163-284): nnz-balanced row blocks with re-based row pointers write A_i*B (alpha=beta=1)
+    into a zeroed Ccopy at row offset start_row with ldc = M; the partials are summed (the all-reduce's
+    arithmetic) and C = beta*C + alpha*Ccopy (kernel.h:27-38) finishes.  Boundary rows are split between two
+    blocks, so only <=1e-10 relative is possible, not bit equality."""
+    sblas, oracle, torch, dev = env
+    N, M = 64, 85
+    rp, ci, v = ash85["rowptr"], ash85["colidx"], ash85["val"]
+    Bh = oracle.rand0to1(M * N)
+    B = torch.from_numpy(Bh).to(dev)
+    ws = torch.empty(M * 64, dtype=torch.float64, device=dev)
+    total = torch.zeros(M * N, dtype=torch.float64, device=dev)
+    for i in range(g):
+        d = sblas.partition_nnz(rp, g, i)
+        lo, k = d["first_nnz"], d["nnz"]
+        Ai = Dev(torch, dev, d["rowptr"], ci[lo:lo + k], v[lo:lo + k], M)
+        ccopy = torch.zeros(M * N, dtype=torch.float64, device=dev)
+        sblas.spmm(Ai.rows, M, Ai.rowptr, Ai.colidx, Ai.val, B, M, N, 1.0, 1.0, ccopy, M, ws, c_offset=d["start_row"])
+        sblas.axpby(M * N, 1.0, ccopy, 1.0, total)          # rank-order sum = what the all-reduce computes
+    C = torch.ones(M * N, dtype=torch.float64, device=dev)
+    sblas.axpby(M * N, 3.0, total, 4.0, C)
+    ref = oracle.spmm(M, M, N, rp, ci, v, Bh, np.ones(M * N), 3.0, 4.0)
+    assert close(C.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("avg", [1, 3, 7, 15, 30, 70, 400])
+def test_spmv_every_row_length_class(env, avg):
+    """One case per lanes-per-row instantiation (4..64), unsorted rows, empty rows, a long row."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    M, K = 1234, 987
+    rp, ci, v = synth.random_csr(M, K, avg, seed=avg, empty_every=13, long_row=(17, 2000))
+    A = Dev(torch, dev, rp, ci, v, K)
+    rng = np.random.default_rng(avg)
+    xh, yh = rng.standard_normal(K), rng.standard_normal(M)
+    for alpha, beta in ((1.0, 1.0), (0.5, -2.0), (3.0, 0.0)):
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
+        ref = oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)
+        assert close(y.cpu().numpy(), ref), (avg, alpha, beta)
+
+
+def test_spmv_row_block_offsets(env, ash85):
+    """spmv.h:85-88: y view = Ccopy + starting_row; same partition + merge as method 2, N = 1."""
+    sblas, oracle, torch, dev = env
+    rp, ci, v = ash85["rowptr"], ash85["colidx"], ash85["val"]
+    x = torch.ones(85, dtype=torch.float64, device=dev)
+    for g in (2, 4, 8):
+        total = torch.zeros(85, dtype=torch.float64, device=dev)
+        for i in range(g):
+            d = sblas.partition_nnz(rp, g, i)
+            lo, k = d["first_nnz"], d["nnz"]
+            Ai = Dev(torch, dev, d["rowptr"], ci[lo:lo + k], v[lo:lo + k], 85)
+            sblas.spmv(Ai.rows, 85, Ai.rowptr, Ai.colidx, Ai.val, x, 1.0, 1.0, total, y_offset=d["start_row"])
+        y = torch.ones(85, dtype=torch.float64, device=dev)
+        sblas.axpby(85, 3.0, total, 4.0, y)
+        ref = oracle.spmv(85, rp, ci, v, np.ones(85), np.ones(85), 3.0, 4.0)
+        assert close(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 256, 257, 100001])
+def test_axpby(env, n):
+    sblas, oracle, torch, dev = env
+    rng = np.random.default_rng(n)
+    xh, yh = rng.standard_normal(n + 1), rng.standard_normal(n + 1)
+    for off in (0, 1):                                  # off=1: 8-byte-aligned only -> scalar path
+        x = torch.from_numpy(xh).to(dev)[off:off + n].contiguous() if off == 0 else torch.from_numpy(xh).to(dev)[1:]
+        y = torch.from_numpy(yh.copy()).to(dev)[off:off + n] if off else torch.from_numpy(yh[:n].copy()).to(dev)
+        x = x[:n]
+        sblas.axpby(n, 0.3, x, -1.7, y)
+        ref = yh[off:off + n].copy()
+        oracle.lib().orc_axpby(n, 0.3, np.ascontiguousarray(xh[off:off + n] if off else xh[:n]), -1.7, ref)
+        assert close(y.cpu().numpy(), ref)
+
+
+def test_full_size_properties(env):
+    """BASELINE config 3 size (72 000 rows, 28.7 M nnz, N = 64), where the oracle would take minutes:
+    size-independent properties instead -- (i) B = ones gives C[i, :] = rowsum(A)[i]; (ii) column j of SpMM
+    equals SpMV with B[:, j]; (iii) linearity in B; plus (iv) an oracle spot check on 192 sampled rows."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, (rp, ci, v) = synth.nd24k_like()
+    N = 64
+    A = Dev(torch, dev, rp, ci, v, rows)
+    ws = torch.empty(rows * 64, dtype=torch.float64, device=dev)
+
+    def run(Bt_, alpha=1.0, beta=0.0, C=None):
+        C = torch.zeros(rows * N, dtype=torch.float64, device=dev) if C is None else C
+        sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, Bt_, rows, N, alpha, beta, C, rows, ws)
+        return C
+
+    # (i) row sums, computed independently with torch on the GPU
+    ones = torch.ones(rows * N, dtype=torch.float64, device=dev)
+    C1 = run(ones).view(N, rows)
+    lens = torch.from_numpy(np.diff(rp).astype(np.int64)).to(dev)
+    rowsum = torch.segment_reduce(A.val, "sum", lengths=lens)
+    assert torch.allclose(C1, rowsum.expand(N, rows), rtol=1e-10, atol=1e-12)
+    # (ii) SpMM column == SpMV
+    g = torch.Generator(device="cpu").manual_seed(211)
+    B = torch.rand(rows * N, dtype=torch.float64, generator=g).to(dev)
+    CB = run(B)
+    for j in (0, 17, 63):
+        y = torch.zeros(rows, dtype=torch.float64, device=dev)
+        sblas.spmv(rows, rows, A.rowptr, A.colidx, A.val, B[j * rows:(j + 1) * rows].contiguous(), 1.0, 0.0, y)
+        assert torch.allclose(CB.view(N, rows)[j], y, rtol=1e-10, atol=1e-12)
+    # (iii) linearity: A(2B + ones) = 2AB + A*ones
+    Clin = run(2.0 * B + ones)
+    assert torch.allclose(Clin, 2.0 * CB + C1.reshape(-1), rtol=1e-10, atol=1e-11)
+    # (iv) oracle on sampled rows (alpha, beta != trivial), same inputs
+    C0 = torch.full((rows * N,), 1.0, dtype=torch.float64, device=dev)
+    got = run(B, 3.0, 4.0, C0).cpu().numpy().reshape(N, rows)
+    Bh = B.cpu().numpy()
+    sample = np.r_[0:64, rows // 2:rows // 2 + 64, rows - 64:rows]
+    ref = np.ones(rows * N)
+    for r0 in (0, rows // 2, rows - 64):
+        oracle.spmm_rows(r0, r0 + 64, rows, rows, N, rp, ci, v, Bh, ref, 3.0, 4.0)
+    assert close(got[:, sample], ref.reshape(N, rows)[:, sample])

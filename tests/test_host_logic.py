@@ -1,0 +1,194 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every declared symbol,
+its loader and partitioners agree bit-for-bit with the oracle, and argument validation returns codes
+instead of launching anything.  No compute call is made here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ASH85, GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol(sblas):
+    hdr = open(os.path.join(ROOT, "include", "sblas_hip.h")).read()
+    declared = set(re.findall(r"\b(sblas_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert declared == set(sblas.EXPORTS), declared ^ set(sblas.EXPORTS)
+    L = sblas.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.sblas_hip_version() >= 100
+
+
+def test_product_never_links_the_oracle():
+    """The shipped library must not depend on oracle/ (no CPU fallback path)."""
+    import subprocess
+    so = os.path.join(ROOT, "s-blas_amd", "lib", "libsblas_hip.so")
+    out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "rccl" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "s-blas_amd")):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h", ".py")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_py" not in text and "liboracle" not in text and "sblas_oracle" not in text, f
+
+
+def test_loader_bit_exact_vs_oracle(sblas, oracle):
+    paths = [ASH85] + sorted(os.path.join(GOLDEN, "loader_cases", f) for f in os.listdir(os.path.join(GOLDEN, "loader_cases")))
+    for p in paths:
+        a, b = sblas.read_mtx(p), oracle.read_mtx(p)
+        assert a[:4] == b[:4], p
+        for x, y in zip(a[4:], b[4:]):
+            assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), p
+
+
+def test_loader_vs_committed_reference_outputs(sblas):
+    with open(os.path.join(GOLDEN, "loader_expected.json")) as f:
+        exp = json.load(f)
+    for name, e in exp.items():
+        if name.startswith("_"):
+            continue
+        m, n, nnz, sym, rp, ci, v = sblas.read_mtx(os.path.join(GOLDEN, "loader_cases", name + ".mtx"))
+        assert (m, n, nnz, sym) == (e["m"], e["n"], e["nnz"], e["symmetric"]), name
+        assert rp.tolist() == e["rowptr"] and ci.tolist() == e["colidx"], name
+        assert [float(x).hex() for x in v] == e["val"], name
+
+
+def test_loader_errors(sblas, tmp_path):
+    with pytest.raises(sblas.SblasError):
+        sblas.read_mtx(str(tmp_path / "missing.mtx"))
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n")   # truncated
+    with pytest.raises(sblas.SblasError):
+        sblas.read_mtx(str(bad))
+    oob = tmp_path / "oob.mtx"
+    oob.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")     # row out of range
+    with pytest.raises(sblas.SblasError):
+        sblas.read_mtx(str(oob))
+
+
+def test_loader_roundtrip_random(sblas, oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    for sym in (False, True):
+        m = 37
+        n = 37 if sym else 23
+        nz = 300
+        i = rng.integers(1, m + 1, nz)
+        j = rng.integers(1, n + 1, nz)
+        if sym:
+            i, j = np.maximum(i, j), np.minimum(i, j)
+        v = rng.standard_normal(nz)
+        p = tmp_path / ("r%d.mtx" % sym)
+        with open(p, "w") as f:
+            f.write("%%%%MatrixMarket matrix coordinate real %s\n%d %d %d\n" % ("symmetric" if sym else "general", m, n, nz))
+            for a, b, c in zip(i, j, v):
+                f.write("%d %d %.17g\n" % (a, b, c))
+        a, b = sblas.read_mtx(str(p)), oracle.read_mtx(str(p))
+        assert a[:4] == b[:4]
+        for x, y in zip(a[4:], b[4:]):
+            assert x.tobytes() == y.tobytes()
+
+
+def test_find_row_matches_linear_scan(sblas, oracle):
+    rng = np.random.default_rng(1)
+    lens = rng.integers(0, 5, 200)
+    lens[[0, 7, 8, 199]] = 0                       # leading / consecutive / trailing empty rows
+    rp = np.zeros(201, np.int32)
+    rp[1:] = np.cumsum(lens)
+    for idx in list(range(int(rp[-1]))) + [-1, int(rp[-1]), int(rp[-1]) + 5]:
+        assert sblas.find_row_of_nnz(rp, idx) == oracle.lib().orc_find_row(rp, 200, idx)
+
+
+def test_partition_nnz_matches_oracle(sblas, oracle, ash85):
+    cases = [(ash85["rowptr"], 85)]
+    rng = np.random.default_rng(2)
+    for rows in (1, 3, 64, 1000):
+        lens = rng.integers(0, 9, rows)
+        lens[rng.integers(0, rows)] += 1
+        rp = np.zeros(rows + 1, np.int32)
+        rp[1:] = np.cumsum(lens)
+        cases.append((rp, rows))
+    for rp, rows in cases:
+        nnz = int(rp[-1])
+        for g in (1, 2, 3, 4, 8):
+            if (g - 1) * ((nnz + g - 1) // g) >= nnz:
+                with pytest.raises(sblas.SblasError):        # a rank would own nothing: refused, not UB
+                    for i in range(g):
+                        sblas.partition_nnz(rp, g, i)
+                continue
+            covered = 0
+            for i in range(g):
+                d = sblas.partition_nnz(rp, g, i)
+                s, e, k, reb, avg = oracle.partition_nnz(rp, rows, nnz, g, i, exact=True)
+                assert (d["start_row"], d["stop_row"], d["nnz"]) == (s, e, k)
+                assert d["rowptr"].tolist() == reb.tolist() and d["first_nnz"] == i * avg
+                assert (np.diff(d["rowptr"]) >= 0).all() and d["rowptr"][-1] == k
+                covered += k
+            assert covered == nnz
+
+
+def test_partition_tables_known_answers(sblas, ash85):
+    with open(os.path.join(GOLDEN, "ash85_golden.json")) as f:
+        gold = json.load(f)
+    for g_str, table in gold["segments"].items():
+        g = int(g_str)
+        got = [[d["start_row"], d["stop_row"], d["nnz"]] for d in (sblas.partition_nnz(ash85["rowptr"], g, i) for i in range(g))]
+        assert got == table
+    for i_str, head in gold["rebased_heads_g4"].items():
+        assert sblas.partition_nnz(ash85["rowptr"], 4, int(i_str))["rowptr"][:6].tolist() == head
+    for g_str, dims in gold["dense_segments_n64"].items():
+        g = int(g_str)
+        assert [sblas.partition_dense(64, g, i)[1] for i in range(g)] == dims
+
+
+def test_partition_dense_matches_oracle_and_never_negative(sblas, oracle):
+    for first in (1, 8, 9, 64, 100, 256):
+        for g in (1, 2, 3, 4, 8):
+            tot = 0
+            for i in range(g):
+                off, dim = sblas.partition_dense(first, g, i)
+                o2, d2 = oracle.partition_dense(first, g, i)
+                assert dim >= 0 and off + dim <= first
+                if d2 >= 0:                      # the reference goes negative for e.g. 9 columns on 8 GPUs
+                    assert (off, dim) == (o2, d2) or d2 == 0
+                tot += dim
+            assert tot == first
+
+
+def test_argument_validation_returns_codes_without_a_gpu(sblas):
+    L = sblas.lib()
+    f = L.sblas_hip_spmm_csr_f64_i32
+    one = C.c_void_p(16)                          # never dereferenced: validation fails first
+    assert f(-1, None, -1, 4, 0, one, one, one, one, 4, 4, 1.0, 0.0, one, 4, one, 1 << 20) == 1
+    assert f(-1, None, 4, 4, 3, None, one, one, one, 4, 4, 1.0, 0.0, one, 4, one, 1 << 20) == 1     # rowptr NULL
+    assert f(-1, None, 4, 4, 3, one, one, one, one, 3, 4, 1.0, 0.0, one, 4, one, 1 << 20) == 1      # ldb < cols
+    assert f(-1, None, 4, 4, 3, one, one, one, one, 4, 4, 1.0, 0.0, one, 3, one, 1 << 20) == 1      # ldc < rows
+    assert f(-1, None, 4, 4, 3, one, one, one, one, 4, 4, 1.0, 0.0, one, 4, None, 0) == 3           # no workspace
+    assert f(-1, None, 0, 4, 0, one, None, None, one, 4, 4, 1.0, 0.0, one, 4, None, 0) == 0         # empty: no-op
+    assert L.sblas_hip_spmv_csr_f64_i32(-1, None, 4, 4, 3, one, one, one, None, 1.0, 0.0, one) == 1
+    assert L.sblas_hip_axpby_f64(-1, None, -5, 1.0, one, 1.0, one) == 1
+    assert L.sblas_hip_spmm_ldbt(64) == 64 and L.sblas_hip_spmm_ldbt(65) == 128 and L.sblas_hip_spmm_ldbt(8) == 8
+    assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 100 * 64 * 8
+    assert b"workspace" in L.sblas_hip_error_string(3)
+
+
+def test_python_binding_refuses_cpu_tensors(sblas):
+    import torch
+    t = torch.zeros(4, dtype=torch.float64)
+    with pytest.raises(sblas.SblasError):
+        sblas.axpby(4, 1.0, t, 1.0, t)
+
+
+def test_synthetic_generators(sblas):
+    from sblas_amd import synth
+    rp, ci, v = synth.banded(500, 40, 100)
+    assert rp[-1] == 500 * 40 and len(ci) == rp[-1]
+    for r in (0, 1, 99, 250, 499):
+        c = ci[rp[r]:rp[r + 1]]
+        assert (np.diff(c) > 0).all() and c.min() >= max(0, r - 100) and c.max() <= min(499, r + 100)
+    rp2, ci2, v2 = synth.banded(500, 40, 100)
+    assert (ci == ci2).all() and (v == v2).all()          # deterministic
+    rp, ci, v = synth.random_csr(100, 50, 7, empty_every=10, long_row=(3, 300))
+    assert rp[4] - rp[3] == 300 and rp[1] - rp[0] == 0 and ci.max() < 50
