@@ -70,28 +70,44 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
 //     lanes running along the row index, which is the contiguous direction of column-major C
 //     (this is also where alpha/beta are applied, so C is read and written exactly once).
 // ---------------------------------------------------------------------------------------------
-constexpr int PANEL_ROWS = 32;
-constexpr int ROWS_PER_WAVE = PANEL_ROWS / 4;
+constexpr int PANEL_ROWS = 32;   // narrow kernels (256 threads)
 
-__global__ __launch_bounds__(256) void spmm_rowpanel_kernel(int rows, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ colidx,
-                                                           const double *__restrict__ val,
-                                                           const double *__restrict__ Bt, int64_t ldbt, int n,
-                                                           double alpha, double beta, double *__restrict__ C,
-                                                           int64_t ldc)
+// Wide kernel geometry: 16 waves (1024 threads), one row per wave at a time -> a 16-row panel.
+// Few rows in flight per CU keeps the set of Bt rows that the resident workgroups of one XCD touch
+// (rows in flight + the matrix band) inside that XCD's 4 MiB L2; with 32-row panels on 256-thread
+// blocks ~65 000 rows were in flight chip-wide and every Bt row came from the Infinity Cache.
+constexpr int WIDE_WAVES = 16;
+constexpr int WIDE_ROWS_PER_WAVE = 1;
+constexpr int WIDE_PANEL = WIDE_WAVES * WIDE_ROWS_PER_WAVE;
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Give every XCD one contiguous
+// range of panels so that neighbouring panels -- which read overlapping Bt rows -- share an L2 (speed only;
+// any placement is correct).  Bijective for every panel count.
+__device__ __forceinline__ int xcd_contiguous_panel(int b, int npanels)
 {
-    __shared__ double ctile[64][PANEL_ROWS + 1];
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = npanels >> 3, r = npanels & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_rowpanel_kernel(
+    int rows, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc)
+{
+    __shared__ double ctile[64][WIDE_PANEL + 1];
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
-    const int row0 = blockIdx.x * PANEL_ROWS;
+    const int row0 = xcd_contiguous_panel(blockIdx.x, npanels) * WIDE_PANEL;
     const int col0 = blockIdx.y * 64;
     // Row c of Bt starts at element c*ldbt: a 32-bit scalar product (cols*ldbt < 2^32 is checked by the
     // C ABI), so the load is "scalar row base + one constant per-lane offset" with no vector address math.
     const unsigned lane_off = (unsigned)(col0 + lane);
     const unsigned ld32 = (unsigned)ldbt;
 
-    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-        const int r = wave * ROWS_PER_WAVE + rr;
+    for (int rr = 0; rr < WIDE_ROWS_PER_WAVE; ++rr) {
+        const int r = wave * WIDE_ROWS_PER_WAVE + rr;
         const int row = row0 + r;
         double acc = 0.0;
         if (row < rows) {
@@ -126,11 +142,11 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_kernel(int rows, const int 
     }
     __syncthreads();
 
-    // write-back: consecutive threads walk consecutive rows of one column of C
-    const int nrows = min(PANEL_ROWS, rows - row0);
+    // write-back: consecutive threads walk consecutive rows of one column of C (128 B per column)
+    const int nrows = min(WIDE_PANEL, rows - row0);
     const int ncols = min(64, n - col0);
-    for (int idx = threadIdx.x; idx < 64 * PANEL_ROWS; idx += 256) {
-        const int r = idx % PANEL_ROWS, j = idx / PANEL_ROWS;
+    for (int idx = threadIdx.x; idx < 64 * WIDE_PANEL; idx += WIDE_WAVES * 64) {
+        const int r = idx % WIDE_PANEL, j = idx / WIDE_PANEL;
         if (r < nrows && j < ncols) {
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
             const double s = alpha * ctile[j][r];
@@ -286,9 +302,10 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, const int *rowptr, cons
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
-        dim3 grid(panels, (unsigned)(ldbt / 64));
-        hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(256), 0, s, rows, rowptr, colidx, val, Bt, ldbt, n,
-                           alpha, beta, C, ldc);
+        const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
+        dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 64));
+        hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(WIDE_WAVES * 64), 0, s, rows, wide_panels, rowptr, colidx,
+                           val, Bt, ldbt, n, alpha, beta, C, ldc);
     } else if (ldbt == 32) {
         hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<32>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
                            val, Bt, n, alpha, beta, C, ldc);

@@ -39,6 +39,10 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SblasError("libsblas_hip.so not built (%s): run __graft_entry__.build() / make -C s-blas_amd" % LIB_PATH)
+    # torch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 / librccl.so.1.  Load torch FIRST so
+    # that our DT_NEEDED entries (and the dlopen of RCCL) resolve by SONAME to the copies already in the process:
+    # two HIP runtimes in one process do not share a device context.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     i64, i32, f64, vp, sz = C.c_int64, C.c_int32, C.c_double, C.c_void_p, C.c_size_t
     L.sblas_hip_version.restype = C.c_int
