@@ -3,6 +3,8 @@
 // come back as SBLAS_E_INVALID, never as a faulting wave.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/sblas_hip.h"
 #include "kernels.h"
 
@@ -27,6 +29,18 @@ struct DeviceScope {
         if (switched) (void)hipSetDevice(prev);
     }
 };
+
+// SBLAS_SPMM_VARIANT=direct|win32|win64|win128 pins the stage-2 kernel (A/B runs, tests); default auto.
+inline int spmm_variant()
+{
+    const char *e = getenv("SBLAS_SPMM_VARIANT");
+    if (!e || !*e) return sblas::SPMM_VARIANT_AUTO;
+    if (!strcmp(e, "direct")) return sblas::SPMM_VARIANT_DIRECT;
+    if (!strcmp(e, "win32")) return sblas::SPMM_VARIANT_WINDOW_R32;
+    if (!strcmp(e, "win64")) return sblas::SPMM_VARIANT_WINDOW_R64;
+    if (!strcmp(e, "win128")) return sblas::SPMM_VARIANT_WINDOW_R128;
+    return sblas::SPMM_VARIANT_AUTO;
+}
 
 inline bool csr_args_ok(int64_t rows, int64_t cols, int64_t nnz, const void *rowptr, const void *colidx,
                         const void *val)
@@ -109,8 +123,9 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     if ((uint64_t)cols * (uint64_t)ldbt > 0xffffffffull) return SBLAS_E_INVALID;
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
-    return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, rowptr, colidx, val, Bt, ldbt, (int)n,
-                                       alpha, beta, C, ldc) == hipSuccess
+    if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID; // 16-byte tile loads
+    return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, (int)cols, rowptr, colidx, val, Bt, ldbt,
+                                       (int)n, alpha, beta, C, ldc, spmm_variant()) == hipSuccess
                ? SBLAS_OK
                : SBLAS_E_HIP;
 }

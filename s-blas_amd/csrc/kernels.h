@@ -12,9 +12,13 @@ struct ReplicaPtrs {
 
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
                                     double *Bt, int64_t ldbt);
-hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, const int *rowptr, const int *colidx,
+// SpMM stage-2 variants (wide form).  AUTO = the windowed row-panel x B-tile kernel with 64-row panels, which
+// falls back per panel to the direct loop; the others exist for A/B measurements and tests.
+enum { SPMM_VARIANT_AUTO = 0, SPMM_VARIANT_DIRECT = 1, SPMM_VARIANT_WINDOW_R32 = 2, SPMM_VARIANT_WINDOW_R64 = 3,
+       SPMM_VARIANT_WINDOW_R128 = 4 };
+hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc);
+                                double beta, double *C, int64_t ldc, int variant);
 hipError_t launch_spmv(hipStream_t s, int rows, int64_t nnz, const int *rowptr, const int *colidx,
                        const double *val, const double *x, double alpha, double beta, double *y);
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y);

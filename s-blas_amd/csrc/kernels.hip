@@ -156,6 +156,261 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_rowpanel_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form: row panel x dense B tile through LDS.
+//
+// The direct kernel above pulls one 512-byte Bt row per nonzero through the vector-memory path
+// (64 B/clk/CU), i.e. >= 8 clk per nonzero per CU.  When the rows of a panel share a narrow column
+// range (banded / well-ordered FEM matrices) the Bt rows can be staged ONCE per panel in LDS and each
+// nonzero then costs one conflict-free ds_read_b64 per lane (256 B/clk/CU):
+//
+//   workgroup = 16 waves = a panel of R = 16*RPW rows x one 64-column tile of C;
+//   the panel's column span [cmin, cmax] is walked in tiles of WIN_W Bt rows (64 KiB each, two LDS
+//   buffers: tile t+1 is fetched into registers while tile t is consumed, and written to LDS after
+//   it -- one barrier per tile);
+//   every wave keeps, for each of its RPW rows, the current 64-nonzero chunk of (col, val) in
+//   registers plus the next chunk prefetched; per tile it consumes the prefix of the chunk whose
+//   columns fall inside the tile (rows with ascending columns: a ballot + popcount).
+//
+// Nothing is assumed about the input: a panel takes this path only if it is dense enough over its
+// span to pay for the tile loads, every consumed nonzero is checked to lie inside the current tile,
+// and a panel that breaks the ascending-column expectation (or ends with unconsumed nonzeros) is
+// recomputed by the direct per-row loop before anything is written to C.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIN_W = 128;                 // Bt rows per LDS tile
+constexpr int WIN_TILE = WIN_W * 64;       // doubles per tile (64 KiB)
+constexpr int WIN_THREADS = 1024;
+constexpr size_t WIN_LDS_BYTES = 2 * WIN_TILE * sizeof(double) + 64 * sizeof(int);
+
+__device__ __forceinline__ void load_chunk(const int *__restrict__ colidx, const double *__restrict__ val, int p,
+                                           int pend, int lane, int &c, double &v)
+{
+    const int idx = p + lane;
+    c = 0x7fffffff; // lanes past the row end never compare below a tile bound
+    v = 0.0;
+    if (idx < pend) {
+        c = colidx[idx];
+        v = val[idx];
+    }
+}
+
+// one row, straight from Bt in L2 (also the per-panel fallback of the windowed kernel)
+__device__ __forceinline__ double row_direct(const int *__restrict__ colidx, const double *__restrict__ val,
+                                             const double *__restrict__ Bt, unsigned ld32, unsigned lane_off,
+                                             int lane, int p0, int p1)
+{
+    double acc = 0.0;
+    for (int p = p0; p < p1; p += WAVE) {
+        const int mine = p + lane;
+        int cj = 0;
+        double vj = 0.0;
+        if (mine < p1) {
+            cj = colidx[mine];
+            vj = val[mine];
+        }
+        const int cnt = min(WAVE, p1 - p);
+        int k = 0;
+        for (; k + 8 <= cnt; k += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = __builtin_amdgcn_readlane(cj, k + u);
+                const double a = readlane_f64(vj, k + u);
+                acc = fma(a, (Bt + (size_t)((unsigned)c * ld32))[lane_off], acc);
+            }
+        }
+        for (; k < cnt; ++k) {
+            const int c = __builtin_amdgcn_readlane(cj, k);
+            const double a = readlane_f64(vj, k);
+            acc = fma(a, (Bt + (size_t)((unsigned)c * ld32))[lane_off], acc);
+        }
+    }
+    return acc;
+}
+
+template <int RPW>
+__global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, float min_density)
+{
+    constexpr int R = 16 * RPW;
+    static_assert(64 * (R + 1) <= 2 * WIN_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * WIN_TILE); // [0]=cmin [1]=cmax [2]=bad
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = xcd_contiguous_panel(blockIdx.x, npanels) * R;
+    const int col0 = blockIdx.y * 64;
+    const unsigned lane_off = (unsigned)(col0 + lane);
+    const unsigned ld32 = (unsigned)ldbt;
+
+    if (tid == 0) {
+        sm_i[0] = 0x7fffffff;
+        sm_i[1] = -1;
+        sm_i[2] = 0;
+    }
+    __syncthreads();
+    if (tid < R) {
+        const int row = row0 + tid;
+        if (row < rows) {
+            const int a = rowptr[row], b = rowptr[row + 1];
+            if (b > a) {
+                atomicMin(&sm_i[0], colidx[a]);     // first / last column: the span when columns ascend;
+                atomicMax(&sm_i[1], colidx[b - 1]); // anything else is caught by the in-tile check below
+            }
+        }
+    }
+    // this wave's rows
+    int p0[RPW], p1[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + wave * RPW + r;
+        p0[r] = p1[r] = 0;
+        if (row < rows) {
+            p0[r] = wave_uniform(rowptr[row]);
+            p1[r] = wave_uniform(rowptr[row + 1]);
+        }
+    }
+    __syncthreads();
+    const int cmin = sm_i[0], cmax = sm_i[1];
+    const int last_row = min(row0 + R, rows);
+    const int panel_nnz = wave_uniform(rowptr[last_row]) - wave_uniform(rowptr[row0]);
+    bool windowed = cmax >= cmin && cmin >= 0 && cmax < cols &&
+                    (float)panel_nnz >= min_density * (float)(cmax - cmin + 1);
+
+    double acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.0;
+
+    if (windowed) {
+        const int t_lo = cmin / WIN_W, t_hi = cmax / WIN_W;
+        // per-row chunk state (registers; all indices static after unrolling)
+        int base[RPW], pos[RPW];
+        int cj[RPW], cn[RPW];
+        double vj[RPW], vn[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            base[r] = p0[r];
+            pos[r] = 0;
+            load_chunk(colidx, val, p0[r], p1[r], lane, cj[r], vj[r]);
+            load_chunk(colidx, val, p0[r] + WAVE, p1[r], lane, cn[r], vn[r]);
+        }
+        int bad = 0;
+
+        // tile staging: 4 x 16 B per thread; chunk q -> Bt row q/32, 16-byte piece q%32
+        double2 stage[4];
+        auto stage_load = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + WIN_THREADS * i;
+                const int brow = t * WIN_W + (q >> 5);
+                double2 x = make_double2(0.0, 0.0);
+                if (brow < cols)
+                    x = *reinterpret_cast<const double2 *>(Bt + (size_t)((unsigned)brow * ld32) + col0 + ((q & 31) << 1));
+                stage[i] = x;
+            }
+        };
+        auto stage_store = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = tid + WIN_THREADS * i;
+                *reinterpret_cast<double2 *>(smem + buf * WIN_TILE + (q << 1)) = stage[i];
+            }
+        };
+
+        stage_load(t_lo);
+        stage_store(0);
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int cur = (t - t_lo) & 1;
+            if (t < t_hi) stage_load(t + 1);
+            __syncthreads(); // tile t is in LDS; nobody still reads the other buffer
+            const int tile_lo = t * WIN_W, tile_hi = tile_lo + WIN_W;
+            const double *tile = smem + cur * WIN_TILE + lane;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                for (;;) {
+                    const int cnt = min(WAVE, p1[r] - base[r]);
+                    if (pos[r] >= cnt) {
+                        if (base[r] + WAVE >= p1[r]) break; // row finished
+                        base[r] += WAVE;                     // next chunk (already in registers)
+                        pos[r] = 0;
+                        cj[r] = cn[r];
+                        vj[r] = vn[r];
+                        load_chunk(colidx, val, base[r] + WAVE, p1[r], lane, cn[r], vn[r]);
+                        continue;
+                    }
+                    const bool live = lane >= pos[r] && lane < cnt;
+                    const unsigned long long m = __ballot(live && cj[r] < tile_hi);
+                    const int take = __popcll(m);
+                    if (take == 0) break; // next nonzero belongs to a later tile
+                    // the taken lanes must be exactly pos..pos+take-1 and lie inside this tile
+                    const unsigned long long want = ((take == 64) ? ~0ull : ((1ull << take) - 1ull)) << pos[r];
+                    const unsigned long long below = __ballot(live && cj[r] < tile_lo);
+                    if (m != want || below != 0ull) {
+                        bad = 1;
+                        pos[r] = cnt;
+                        base[r] = p1[r]; // park the row; the panel will be recomputed
+                        break;
+                    }
+                    const int k_end = pos[r] + take;
+                    int k = pos[r];
+                    double a_acc = acc[r];
+                    for (; k + 4 <= k_end; k += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int c = __builtin_amdgcn_readlane(cj[r], k + u) - tile_lo;
+                            const double a = readlane_f64(vj[r], k + u);
+                            a_acc = fma(a, tile[c * 64], a_acc);
+                        }
+                    }
+                    for (; k < k_end; ++k) {
+                        const int c = __builtin_amdgcn_readlane(cj[r], k) - tile_lo;
+                        const double a = readlane_f64(vj[r], k);
+                        a_acc = fma(a, tile[c * 64], a_acc);
+                    }
+                    acc[r] = a_acc;
+                    pos[r] = k_end;
+                    if (k_end < cnt) break; // chunk not exhausted: the rest is for later tiles
+                }
+            }
+            if (t < t_hi) stage_store(cur ^ 1);
+        }
+        // every nonzero of every row must have been consumed
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            if (base[r] + pos[r] < p1[r]) bad = 1;
+        if (bad && lane == 0) atomicOr(&sm_i[2], 1);
+        __syncthreads(); // also: all tile reads are done, the buffers may be reused for the C tile
+        if (sm_i[2] != 0) {
+            windowed = false;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) acc[r] = 0.0;
+        }
+    }
+    if (!windowed) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[r] = row_direct(colidx, val, Bt, ld32, lane_off, lane, p0[r], p1[r]);
+    }
+
+    // park the panel as [column][row] (aliases the tile buffers, now dead) and write it back along rows
+    double *ctile = smem;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) ctile[lane * (R + 1) + wave * RPW + r] = acc[r];
+    __syncthreads();
+    const int nrows = min(R, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * R; idx += WIN_THREADS) {
+        const int r = idx % R, j = idx / R;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double s = alpha * ctile[j * (R + 1) + r];
+            *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 2, narrow form (ldbt = G in {8,16,32}, n <= G): a group of G lanes owns a row, so a wave
 // works on 64/G rows at once and every lane fetches its row's (col, val) itself (the G lanes of a
 // group read the same address, which the memory pipeline serves as one request).
@@ -296,16 +551,39 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
     return hipGetLastError();
 }
 
-hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, const int *rowptr, const int *colidx,
+hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc)
+                                double beta, double *C, int64_t ldc, int variant)
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
-        const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
-        dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 64));
-        hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(WIDE_WAVES * 64), 0, s, rows, wide_panels, rowptr, colidx,
-                           val, Bt, ldbt, n, alpha, beta, C, ldc);
+        if (variant == SPMM_VARIANT_DIRECT) {
+            const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
+            dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 64));
+            hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(WIDE_WAVES * 64), 0, s, rows, wide_panels, rowptr,
+                               colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
+        } else {
+            const int rpw = (variant == SPMM_VARIANT_WINDOW_R32) ? 2 : (variant == SPMM_VARIANT_WINDOW_R128) ? 8 : 4;
+            const int R = 16 * rpw;
+            const int np = (rows + R - 1) / R;
+            dim3 grid((unsigned)np, (unsigned)(ldbt / 64));
+            const float dens = 2.0f; // window a panel when it holds >= 2 nonzeros per Bt row of its span
+#define SBLAS_WIN_LAUNCH(RPW)                                                                                        \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)spmm_window_kernel<RPW>,                                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES);               \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(spmm_window_kernel<RPW>, grid, dim3(WIN_THREADS), WIN_LDS_BYTES, s, rows, cols, np,       \
+                           rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, dens);                             \
+    } while (0)
+            if (rpw == 2) SBLAS_WIN_LAUNCH(2);
+            else if (rpw == 8) SBLAS_WIN_LAUNCH(8);
+            else SBLAS_WIN_LAUNCH(4);
+#undef SBLAS_WIN_LAUNCH
+        }
     } else if (ldbt == 32) {
         hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<32>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
                            val, Bt, n, alpha, beta, C, ldc);

@@ -324,3 +324,114 @@ def test_full_size_properties(env):
     for r0 in (0, rows // 2, rows - 64):
         oracle.spmm_rows(r0, r0 + 64, rows, rows, N, rp, ci, v, Bh, ref, 3.0, 4.0)
     assert close(got[:, sample], ref.reshape(N, rows)[:, sample])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the windowed (row panel x LDS B tile) kernel and its per-panel fallback
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def variant_env():
+    old = os.environ.get("SBLAS_SPMM_VARIANT")
+    yield lambda v: os.environ.__setitem__("SBLAS_SPMM_VARIANT", v)
+    if old is None:
+        os.environ.pop("SBLAS_SPMM_VARIANT", None)
+    else:
+        os.environ["SBLAS_SPMM_VARIANT"] = old
+
+
+@pytest.mark.parametrize("variant", ["direct", "win32", "win64", "win128", "auto"])
+@pytest.mark.parametrize("shape", [(1000, 40, 100, 64), (777, 60, 300, 130), (200, 30, 20, 64), (90, 80, 45, 256)])
+def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
+    """Banded, ascending rows: dense enough over their span that the windowed path is taken.  Covers several
+    tiles per panel, K not a multiple of the 128-row tile, K < one tile, N > 64 (column tiles) and padding."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, per_row, half, n = shape
+    variant_env(variant)
+    rp, ci, v = synth.banded(rows, per_row, half)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(rows)
+    B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.25, -0.5, C0, rows)
+    ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.25, -0.5)
+    assert close(got, ref), (variant, shape, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("variant", ["win32", "win64", "win128"])
+@pytest.mark.parametrize("damage", ["all_descending", "one_row_shuffled", "first_col_not_min", "duplicates"])
+def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, damage):
+    """The windowed path expects ascending columns but must never depend on it: panels whose rows break the
+    expectation are detected in-kernel and recomputed by the direct loop before C is written."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    rows, n = 600, 64
+    rp, ci, v = synth.banded(rows, 50, 120)
+    ci, v = ci.copy(), v.copy()
+    rng = np.random.default_rng(11)
+    if damage == "all_descending":
+        for r in range(rows):
+            ci[rp[r]:rp[r + 1]] = ci[rp[r]:rp[r + 1]][::-1]
+            v[rp[r]:rp[r + 1]] = v[rp[r]:rp[r + 1]][::-1]
+    elif damage == "one_row_shuffled":
+        for r in (5, 300, 599):
+            perm = rng.permutation(rp[r + 1] - rp[r])
+            ci[rp[r]:rp[r + 1]] = ci[rp[r]:rp[r + 1]][perm]
+            v[rp[r]:rp[r + 1]] = v[rp[r]:rp[r + 1]][perm]
+    elif damage == "first_col_not_min":
+        for r in range(0, rows, 7):                 # swap first and last entry: span estimate is wrong
+            a, b = rp[r], rp[r + 1] - 1
+            ci[a], ci[b] = ci[b], ci[a]
+            v[a], v[b] = v[b], v[a]
+    else:                                           # repeated column indices inside ascending rows
+        for r in range(0, rows, 3):
+            ci[rp[r] + 1] = ci[rp[r]]
+            ci[rp[r + 1] - 1] = ci[rp[r + 1] - 2]
+    A = Dev(torch, dev, rp, ci, v, rows)
+    B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
+    ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
+    assert close(got, ref), (variant, damage, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("variant", ["win32", "win64", "win128"])
+def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
+    """Dense-band panels next to sparse wide-span panels (direct path chosen per panel), empty rows, rows longer
+    than several chunks, and a method-2 style row block (re-based row pointers, C offset, ldc > rows)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    rows, K, n = 512, 3000, 64
+    rng = np.random.default_rng(21)
+    lens = np.where(np.arange(rows) % 128 < 64, 200, 3).astype(np.int64)      # alternating dense / sparse panels
+    lens[10] = 0
+    lens[70] = 0
+    lens[200] = 900
+    rp = np.zeros(rows + 1, np.int64)
+    rp[1:] = np.cumsum(lens)
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(rows):
+        if lens[r] >= 100:
+            lo = min(r * 4, K - 1000)
+            ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(np.arange(lo, lo + 1000), lens[r], replace=False))
+        else:
+            ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(K, lens[r], replace=False))
+    v = rng.standard_normal(rp[-1])
+    A = Dev(torch, dev, rp.astype(np.int32), ci, v, K)
+    B, C0 = rng.standard_normal(K * n), rng.standard_normal(rows * n)
+    got = gpu_spmm(sblas, torch, dev, A, B, K, n, 2.0, 0.5, C0, rows)
+    ref = oracle.spmm(rows, K, n, *A.h, B, C0.copy(), 2.0, 0.5)
+    assert close(got, ref)
+    # row block [100, 400) written at offset into a taller C
+    sub = rp[100:401] - rp[100]
+    As = Dev(torch, dev, sub.astype(np.int32), ci[rp[100]:rp[400]], v[rp[100]:rp[400]], K)
+    Cbig = rng.standard_normal(rows * n)
+    Bd = torch.from_numpy(B).to(dev)
+    Cd = torch.from_numpy(Cbig.copy()).to(dev)
+    ws = torch.empty(K * 64, dtype=torch.float64, device=dev)
+    sblas.spmm(300, K, As.rowptr, As.colidx, As.val, Bd, K, n, 1.0, 1.0, Cd, rows, ws, c_offset=100)
+    want = Cbig.copy().reshape(n, rows)
+    part = np.zeros(300 * n)
+    oracle.spmm(300, K, n, *As.h, B, part, 1.0, 0.0)
+    want[:, 100:400] += part.reshape(n, 300)
+    assert close(Cd.cpu().numpy(), want.reshape(-1))
