@@ -129,7 +129,7 @@ def main():
     B = Bh.to(dev)
     C = torch.ones(rows * n, dtype=torch.float64, device=dev)
     ldbt = int(S.lib().sblas_hip_spmm_ldbt(n))
-    Bt = torch.empty(cols * ldbt, dtype=torch.float64, device=dev)   # the C ABI's workspace
+    Bt = torch.empty(S.spmm_workspace_bytes(rows, cols, nnz, n) // 8, dtype=torch.float64, device=dev)   # the C ABI's workspace
 
     def step():
         # == sblas_hip_spmm_csr_f64_i32: the same two launches, issued separately only so that an event can

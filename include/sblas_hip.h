@@ -76,6 +76,11 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
                                          const double *Bt, int64_t ldbt, int64_t n,
                                          double alpha, double beta, double *C, int64_t ldc);
 
+/* Diagnostics (synchronises the current device): how many row panels of the SpMM launches since the last reset
+ * took the LDS-windowed path [0], the direct path because they are too sparse over their column span [1], or were
+ * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2].  out[3] = 0. */
+int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
+
 /* ---------------------------------------------------------------------------------------
  * SpMV:  y = alpha * A * x + beta * y
  * Replaces cusparseSpMV_bufferSize + cusparseSpMV at spmv.h:94-106 (no workspace is needed).

@@ -36,9 +36,12 @@ inline int spmm_variant()
     const char *e = getenv("SBLAS_SPMM_VARIANT");
     if (!e || !*e) return sblas::SPMM_VARIANT_AUTO;
     if (!strcmp(e, "direct")) return sblas::SPMM_VARIANT_DIRECT;
+    if (!strcmp(e, "dpp")) return sblas::SPMM_VARIANT_DIRECT_DPP;
     if (!strcmp(e, "win32")) return sblas::SPMM_VARIANT_WINDOW_R32;
     if (!strcmp(e, "win64")) return sblas::SPMM_VARIANT_WINDOW_R64;
     if (!strcmp(e, "win128")) return sblas::SPMM_VARIANT_WINDOW_R128;
+    if (!strcmp(e, "win64w64")) return sblas::SPMM_VARIANT_WINDOW_R64W64;
+    if (!strcmp(e, "win32w128")) return sblas::SPMM_VARIANT_WINDOW_R32W128;
     return sblas::SPMM_VARIANT_AUTO;
 }
 
@@ -85,7 +88,8 @@ int64_t sblas_hip_spmm_ldbt(int64_t n)
     if (n <= 8) return 8;
     if (n <= 16) return 16;
     if (n <= 32) return 32;
-    return (n + 63) / 64 * 64;
+    if (n <= 64) return 64;
+    return (n + 127) / 128 * 128; // wide tiles are 128 columns (two per lane)
 }
 
 size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
@@ -93,7 +97,8 @@ size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t 
     (void)rows;
     (void)nnz;
     if (cols <= 0 || n <= 0) return 0;
-    return (size_t)cols * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
+    // one extra, all-zero row: the target of masked DPP slots in the kernels
+    return ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
 }
 
 int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n, const double *B,
@@ -120,7 +125,7 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     if (ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
     if (cols > 0 && !Bt) return SBLAS_E_INVALID;
     // the kernels address Bt with 32-bit element offsets (row * ldbt + column)
-    if ((uint64_t)cols * (uint64_t)ldbt > 0xffffffffull) return SBLAS_E_INVALID;
+    if (((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_E_INVALID; // 32-bit byte offsets
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID; // 16-byte tile loads
@@ -147,6 +152,15 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (rc != SBLAS_OK) return rc;
     return sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n,
                                                 alpha, beta, C, ldc);
+}
+
+int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset)
+{
+    if (!out) return SBLAS_E_INVALID;
+    unsigned long long tmp[4];
+    if (sblas::panel_stats(tmp, reset != 0) != hipSuccess) return SBLAS_E_HIP;
+    for (int i = 0; i < 4; ++i) out[i] = tmp[i];
+    return SBLAS_OK;
 }
 
 int sblas_hip_spmv_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,

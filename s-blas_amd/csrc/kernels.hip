@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
     for (int kk = ty; kk < 64; kk += 4) {
         const int64_t k = k0 + kk, j = j0 + tx;
         if (k < cols && j < ldbt) Bt[k * ldbt + j] = tile[tx][kk];
+        if (k == cols && j < ldbt) Bt[k * ldbt + j] = 0.0; // the all-zero row masked DPP slots point at
     }
 }
 
@@ -176,10 +177,69 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_rowpanel_kernel(
 // and a panel that breaks the ascending-column expectation (or ends with unconsumed nonzeros) is
 // recomputed by the direct per-row loop before anything is written to C.
 // ---------------------------------------------------------------------------------------------
-constexpr int WIN_W = 128;                 // Bt rows per LDS tile
-constexpr int WIN_TILE = WIN_W * 64;       // doubles per tile (64 KiB)
+// panel census of the windowed kernel: [0] windowed, [1] direct (too sparse over its span), [2] windowed but
+// recomputed by the fallback.  One atomic per panel; read through sblas_hip_debug_spmm_panel_stats.
+__device__ unsigned long long g_panel_stats[4];
+
 constexpr int WIN_THREADS = 1024;
-constexpr size_t WIN_LDS_BYTES = 2 * WIN_TILE * sizeof(double) + 64 * sizeof(int);
+// two B tiles + one all-zero Bt row (target of masked DPP slots) + a few ints
+constexpr size_t win_lds_bytes(int W) { return (2 * (size_t)W * 64 + 64) * sizeof(double) + 64 * sizeof(int); }
+
+// Four nonzeros at DPP slots K0..K0+3 of every 16-lane row:
+//   addr_k = row_newbcast:k(co) + lb      (co = byte offset of the nonzero's Bt row inside the tile)
+//   acc   += row_newbcast:k(gv) * LDS[addr_k]
+// v_add_u32_dpp / v_fmac_f64_dpp are full-rate VOP2 ops; v_readlane_b32 (the obvious broadcast) measured
+// ~8 cycles per wave-instruction on gfx950 and made the kernel VALU-bound.  The leading s_nop covers the
+// "VALU write -> DPP read" hazard on co / gv; the LDS reads are counted by hand inside the statement.
+#define SBLAS_DPP4(K0, K1, K2, K3)                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp %[a0], %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a1], %[co], %[lb] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a2], %[co], %[lb] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a3], %[co], %[lb] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "ds_read_b64 %[d0], %[a0]\n\t"                                                                      \
+                 "ds_read_b64 %[d1], %[a1]\n\t"                                                                      \
+                 "ds_read_b64 %[d2], %[a2]\n\t"                                                                      \
+                 "ds_read_b64 %[d3], %[a3]\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[acc], %[gv], %[d0] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[acc], %[gv], %[d1] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[acc], %[gv], %[d2] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"           \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[acc], %[gv], %[d3] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"           \
+                 : [acc] "+v"(acc), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),                  \
+                   [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)                                    \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory")
+
+// Consume nonzeros [g0, g0+ng) (ng <= 16) of a 64-wide register chunk against the LDS tile whose first Bt row
+// is tile_lo.  The segment is first copied into slots 0..ng-1 of every 16-lane DPP row (ds_bpermute, no LDS
+// traffic); slots >= ng get value 0 and the address of the all-zero row, so they add exactly 0.
+__device__ __forceinline__ void consume_dpp16(double &acc, int cj, double vj, int g0, int ng, int tile_lo,
+                                              unsigned lb, unsigned zero_rel, int lane)
+{
+    const int sub = lane & 15;
+    const int src = (g0 + sub) << 2;
+    const int gc = __builtin_amdgcn_ds_bpermute(src, cj);
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(vj));
+    const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(vj));
+    const bool on = sub < ng;
+    const unsigned co = on ? ((unsigned)(gc - tile_lo) << 9) : zero_rel;
+    const double gv = on ? __hiloint2double(hi, lo) : 0.0;
+    unsigned a0, a1, a2, a3;
+    double d0, d1, d2, d3;
+    SBLAS_DPP4(0, 1, 2, 3);
+    if (ng > 4) {
+        SBLAS_DPP4(4, 5, 6, 7);
+        if (ng > 8) {
+            SBLAS_DPP4(8, 9, 10, 11);
+            if (ng > 12) SBLAS_DPP4(12, 13, 14, 15);
+        }
+    }
+}
+
 
 __device__ __forceinline__ void load_chunk(const int *__restrict__ colidx, const double *__restrict__ val, int p,
                                            int pend, int lane, int &c, double &v)
@@ -226,16 +286,21 @@ __device__ __forceinline__ double row_direct(const int *__restrict__ colidx, con
     return acc;
 }
 
-template <int RPW>
-__global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
+template <int RPW, int WIN_W, int MIN_WAVES>
+__global__ __launch_bounds__(WIN_THREADS, MIN_WAVES) void spmm_window_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, float min_density)
 {
     constexpr int R = 16 * RPW;
+    constexpr int WIN_TILE = WIN_W * 64;        // doubles per tile
+    constexpr int STAGE = WIN_TILE / 2 / WIN_THREADS; // 16-byte pieces per thread per tile
+    static_assert(STAGE >= 1, "tile too small for the block");
     static_assert(64 * (R + 1) <= 2 * WIN_TILE, "C tile must fit in the (dead) B tile buffers");
+    static_assert(WIN_W * 512 < (1 << 24), "tile byte offsets must fit the DPP address add");
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    int *sm_i = reinterpret_cast<int *>(smem + 2 * WIN_TILE); // [0]=cmin [1]=cmax [2]=bad
+    double *zero_row = smem + 2 * WIN_TILE;                              // 64 zeros
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * WIN_TILE + 64);        // [0]=cmin [1]=cmax [2]=bad
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -250,6 +315,7 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
         sm_i[1] = -1;
         sm_i[2] = 0;
     }
+    if (tid < 64) zero_row[tid] = 0.0;
     __syncthreads();
     if (tid < R) {
         const int row = row0 + tid;
@@ -299,10 +365,10 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
         int bad = 0;
 
         // tile staging: 4 x 16 B per thread; chunk q -> Bt row q/32, 16-byte piece q%32
-        double2 stage[4];
+        double2 stage[STAGE];
         auto stage_load = [&](int t) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < STAGE; ++i) {
                 const int q = tid + WIN_THREADS * i;
                 const int brow = t * WIN_W + (q >> 5);
                 double2 x = make_double2(0.0, 0.0);
@@ -313,7 +379,7 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
         };
         auto stage_store = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < STAGE; ++i) {
                 const int q = tid + WIN_THREADS * i;
                 *reinterpret_cast<double2 *>(smem + buf * WIN_TILE + (q << 1)) = stage[i];
             }
@@ -326,7 +392,10 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
             if (t < t_hi) stage_load(t + 1);
             __syncthreads(); // tile t is in LDS; nobody still reads the other buffer
             const int tile_lo = t * WIN_W, tile_hi = tile_lo + WIN_W;
-            const double *tile = smem + cur * WIN_TILE + lane;
+            // LDS byte address of this lane's column in row 0 of the current tile, and the zero row relative to it
+            const unsigned tile_base = (unsigned)(uintptr_t)(smem + cur * WIN_TILE);
+            const unsigned lb = tile_base + (unsigned)lane * 8u;
+            const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 for (;;) {
@@ -354,21 +423,9 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
                         break;
                     }
                     const int k_end = pos[r] + take;
-                    int k = pos[r];
                     double a_acc = acc[r];
-                    for (; k + 4 <= k_end; k += 4) {
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c = __builtin_amdgcn_readlane(cj[r], k + u) - tile_lo;
-                            const double a = readlane_f64(vj[r], k + u);
-                            a_acc = fma(a, tile[c * 64], a_acc);
-                        }
-                    }
-                    for (; k < k_end; ++k) {
-                        const int c = __builtin_amdgcn_readlane(cj[r], k) - tile_lo;
-                        const double a = readlane_f64(vj[r], k);
-                        a_acc = fma(a, tile[c * 64], a_acc);
-                    }
+                    for (int g0 = pos[r]; g0 < k_end; g0 += 16)
+                        consume_dpp16(a_acc, cj[r], vj[r], g0, min(16, k_end - g0), tile_lo, lb, zero_rel, lane);
                     acc[r] = a_acc;
                     pos[r] = k_end;
                     if (k_end < cnt) break; // chunk not exhausted: the rest is for later tiles
@@ -388,6 +445,7 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
             for (int r = 0; r < RPW; ++r) acc[r] = 0.0;
         }
     }
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[windowed ? 0 : (sm_i[2] != 0 ? 2 : 1)], 1ull);
     if (!windowed) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) acc[r] = row_direct(colidx, val, Bt, ld32, lane_off, lane, p0[r], p1[r]);
@@ -406,6 +464,142 @@ __global__ __launch_bounds__(WIN_THREADS) void spmm_window_kernel(
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
             const double s = alpha * ctile[j * (R + 1) + r];
             *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, direct form with DPP broadcast (any matrix; no assumption on column order or locality).
+//
+// A wave owns a row and a 128-column tile of C: every lane holds TWO adjacent columns, so a Bt row segment
+// is fetched with one 16-byte load per lane (a wave64 load instruction occupies the address unit for 16
+// cycles whatever its width, so 8-byte loads halve the vector-memory data rate).  For a 64-column tile
+// (HALF) the two 32-lane halves work on two different nonzeros of the same row at once and are added at
+// the end.  The 64-nonzero register chunk is redistributed with ds_bpermute so that every 16-lane DPP row
+// holds 16 consecutive nonzeros (rows 0-1: nonzeros e..e+15, rows 2-3: e+16..e+31 when HALF, else all four
+// rows the same 16); `row_newbcast:k` then feeds nonzero k to every lane of a row at full VALU rate:
+//     off_k = row_newbcast:k(col*ldbt*8) + lane_byte      (v_add_u32_dpp)
+//     b     = 16 bytes at Bt + off_k                       (global_load_dwordx4, scalar base + vector offset)
+//     acc0 += row_newbcast:k(val) * b.x ; acc1 += ... b.y  (v_fmac_f64_dpp)
+// Slots past the end of the row carry value 0 and the offset of the all-zero row Bt[cols].
+// ---------------------------------------------------------------------------------------------
+#define SBLAS_DPP_OFF4(K0, K1, K2, K3, O0, O1, O2, O3)                                                               \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp %[o0], %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[o1], %[co], %[lb] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[o2], %[co], %[lb] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[o3], %[co], %[lb] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 : [o0] "=&v"(O0), [o1] "=&v"(O1), [o2] "=&v"(O2), [o3] "=&v"(O3)                                    \
+                 : [co] "v"(co), [lb] "v"(lb))
+
+#define SBLAS_DPP_FMA4x2(K0, K1, K2, K3, B0, B1, B2, B3)                                                             \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[x0] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[y0] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[x1] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[y1] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[x2] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[y2] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[x3] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[y3] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 : [c0] "+v"(acc0), [c1] "+v"(acc1)                                                                  \
+                 : [gv] "v"(gv), [x0] "v"(B0.x), [y0] "v"(B0.y), [x1] "v"(B1.x), [y1] "v"(B1.y), [x2] "v"(B2.x),    \
+                   [y2] "v"(B2.y), [x3] "v"(B3.x), [y3] "v"(B3.y))
+
+template <bool HALF>
+__global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc)
+{
+    constexpr int TILE_COLS = HALF ? 64 : 128;
+    constexpr int PER_STEP = HALF ? 32 : 16; // nonzeros handled by one 16-slot sweep
+    __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    const int row0 = xcd_contiguous_panel(blockIdx.x, npanels) * WIDE_PANEL;
+    const int col0 = blockIdx.y * TILE_COLS;
+    const int row = row0 + wave;
+    const int sub = lane & 15;
+    const int half = HALF ? (lane >> 5) : 0;
+    const unsigned ldb8 = (unsigned)ldbt * 8u;                                       // bytes per Bt row
+    const unsigned lb = (unsigned)(col0 * 8) + (unsigned)(HALF ? (lane & 31) : lane) * 16u; // this lane's 2 columns
+    const unsigned zero_off = (unsigned)cols * ldb8;                                 // Bt[cols][*] == 0
+    const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
+
+    double acc0 = 0.0, acc1 = 0.0;
+    if (row < rows) {
+        const int p0 = wave_uniform(rowptr[row]);
+        const int p1 = wave_uniform(rowptr[row + 1]);
+        for (int p = p0; p < p1; p += WAVE) {
+            const int mine = p + lane;
+            int cj = 0;
+            double vj = 0.0;
+            if (mine < p1) {
+                cj = colidx[mine];
+                vj = val[mine];
+            }
+            const int cnt = min(WAVE, p1 - p);
+            for (int g0 = 0; g0 < cnt; g0 += PER_STEP) {
+                // slot `sub` of my DPP row takes chunk entry e
+                const int e = g0 + half * 16 + sub;
+                const int src = e << 2;
+                const int gc = __builtin_amdgcn_ds_bpermute(src, cj);
+                const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(vj));
+                const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(vj));
+                const bool on = e < cnt;
+                const unsigned co = on ? (unsigned)gc * ldb8 : zero_off;
+                const double gv = on ? __hiloint2double(hi, lo) : 0.0;
+                const int ng = min(16, cnt - g0); // live slots of the lower half's rows (>= the upper half's)
+                unsigned o0, o1, o2, o3, o4, o5, o6, o7;
+                double2 b0, b1, b2, b3, b4, b5, b6, b7;
+#define SBLAS_LD(O) (*reinterpret_cast<const double2 *>(bt_bytes + (O)))
+                SBLAS_DPP_OFF4(0, 1, 2, 3, o0, o1, o2, o3);
+                b0 = SBLAS_LD(o0); b1 = SBLAS_LD(o1); b2 = SBLAS_LD(o2); b3 = SBLAS_LD(o3);
+                if (ng > 4) {
+                    SBLAS_DPP_OFF4(4, 5, 6, 7, o4, o5, o6, o7);
+                    b4 = SBLAS_LD(o4); b5 = SBLAS_LD(o5); b6 = SBLAS_LD(o6); b7 = SBLAS_LD(o7);
+                    SBLAS_DPP_FMA4x2(0, 1, 2, 3, b0, b1, b2, b3);
+                    if (ng > 8) {
+                        SBLAS_DPP_OFF4(8, 9, 10, 11, o0, o1, o2, o3);
+                        b0 = SBLAS_LD(o0); b1 = SBLAS_LD(o1); b2 = SBLAS_LD(o2); b3 = SBLAS_LD(o3);
+                        SBLAS_DPP_FMA4x2(4, 5, 6, 7, b4, b5, b6, b7);
+                        if (ng > 12) {
+                            SBLAS_DPP_OFF4(12, 13, 14, 15, o4, o5, o6, o7);
+                            b4 = SBLAS_LD(o4); b5 = SBLAS_LD(o5); b6 = SBLAS_LD(o6); b7 = SBLAS_LD(o7);
+                            SBLAS_DPP_FMA4x2(8, 9, 10, 11, b0, b1, b2, b3);
+                            SBLAS_DPP_FMA4x2(12, 13, 14, 15, b4, b5, b6, b7);
+                        } else {
+                            SBLAS_DPP_FMA4x2(8, 9, 10, 11, b0, b1, b2, b3);
+                        }
+                    } else {
+                        SBLAS_DPP_FMA4x2(4, 5, 6, 7, b4, b5, b6, b7);
+                    }
+                } else {
+                    SBLAS_DPP_FMA4x2(0, 1, 2, 3, b0, b1, b2, b3);
+                }
+#undef SBLAS_LD
+            }
+        }
+    }
+    if (HALF) { // the two halves summed different nonzeros of the same row
+        acc0 += __shfl_xor(acc0, 32, WAVE);
+        acc1 += __shfl_xor(acc1, 32, WAVE);
+    }
+    if (!HALF || lane < 32) {
+        const int cl = 2 * (HALF ? (lane & 31) : lane);
+        ctile[cl][wave] = acc0;
+        ctile[cl + 1][wave] = acc1;
+    }
+    __syncthreads();
+    const int nrows = min(WIDE_PANEL, rows - row0);
+    const int ncols = min(TILE_COLS, n - col0);
+    for (int idx = threadIdx.x; idx < TILE_COLS * WIDE_PANEL; idx += WIDE_WAVES * 64) {
+        const int r = idx % WIDE_PANEL, j = idx / WIDE_PANEL;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j][r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
         }
     }
 }
@@ -546,7 +740,7 @@ static inline unsigned capped_grid(int64_t work_items, int per_block)
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
                                     double *Bt, int64_t ldbt)
 {
-    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((ldbt + 63) / 64));
+    dim3 grid((unsigned)((cols + 1 + 63) / 64), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt);
     return hipGetLastError();
 }
@@ -557,31 +751,45 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *ro
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
-        if (variant == SPMM_VARIANT_DIRECT) {
+        if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO) {
+            const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
+            if (ldbt == 64) {
+                dim3 grid((unsigned)wide_panels, 1u);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<true>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
+            } else {
+                dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 128));
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<false>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
+            }
+        } else if (variant == SPMM_VARIANT_DIRECT) {
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
             dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 64));
             hipLaunchKernelGGL(spmm_rowpanel_kernel, grid, dim3(WIDE_WAVES * 64), 0, s, rows, wide_panels, rowptr,
                                colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
         } else {
-            const int rpw = (variant == SPMM_VARIANT_WINDOW_R32) ? 2 : (variant == SPMM_VARIANT_WINDOW_R128) ? 8 : 4;
-            const int R = 16 * rpw;
-            const int np = (rows + R - 1) / R;
-            dim3 grid((unsigned)np, (unsigned)(ldbt / 64));
             const float dens = 2.0f; // window a panel when it holds >= 2 nonzeros per Bt row of its span
-#define SBLAS_WIN_LAUNCH(RPW)                                                                                        \
+#define SBLAS_WIN_LAUNCH(RPW, W, MW)                                                                                 \
     do {                                                                                                             \
+        constexpr int R = 16 * RPW;                                                                                  \
+        const int np = (rows + R - 1) / R;                                                                           \
+        dim3 grid((unsigned)np, (unsigned)(ldbt / 64));                                                              \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)spmm_window_kernel<RPW>,                                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIN_LDS_BYTES);               \
+            (void)hipFuncSetAttribute((const void *)spmm_window_kernel<RPW, W, MW>,                                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds_bytes(W));            \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL(spmm_window_kernel<RPW>, grid, dim3(WIN_THREADS), WIN_LDS_BYTES, s, rows, cols, np,       \
-                           rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, dens);                             \
+        hipLaunchKernelGGL((spmm_window_kernel<RPW, W, MW>), grid, dim3(WIN_THREADS), win_lds_bytes(W), s, rows,     \
+                           cols, np, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, dens);                   \
     } while (0)
-            if (rpw == 2) SBLAS_WIN_LAUNCH(2);
-            else if (rpw == 8) SBLAS_WIN_LAUNCH(8);
-            else SBLAS_WIN_LAUNCH(4);
+            switch (variant) {
+            case SPMM_VARIANT_WINDOW_R32: SBLAS_WIN_LAUNCH(2, 64, 8); break;   // 64 KiB LDS, 2 blocks/CU
+            case SPMM_VARIANT_WINDOW_R128: SBLAS_WIN_LAUNCH(8, 128, 4); break; // 128 KiB LDS, 1 block/CU
+            case SPMM_VARIANT_WINDOW_R64W64: SBLAS_WIN_LAUNCH(4, 64, 8); break;
+            case SPMM_VARIANT_WINDOW_R32W128: SBLAS_WIN_LAUNCH(2, 128, 4); break;
+            default: SBLAS_WIN_LAUNCH(4, 128, 4); break;
+            }
 #undef SBLAS_WIN_LAUNCH
         }
     } else if (ldbt == 32) {
@@ -595,6 +803,16 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *ro
                            val, Bt, n, alpha, beta, C, ldc);
     }
     return hipGetLastError();
+}
+
+hipError_t panel_stats(unsigned long long out[4], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stats), 4 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_panel_stats), z, sizeof z);
+    }
+    return e;
 }
 
 template <int LPR>

@@ -18,7 +18,7 @@ EXPORTS = [
     "sblas_hip_version", "sblas_hip_error_string", "sblas_hip_device_count",
     "sblas_hip_spmm_csr_f64_i32_workspace", "sblas_hip_spmm_csr_f64_i32", "sblas_hip_spmm_ldbt",
     "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
-    "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
+    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
     "sblas_mm_read_info", "sblas_mm_read_csr",
@@ -59,6 +59,8 @@ def lib():
     L.sblas_hip_dense_to_rowmajor_f64.argtypes = [C.c_int, vp, i64, i64, vp, i64, vp, i64]
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.restype = C.c_int
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64]
+    L.sblas_hip_debug_spmm_panel_stats.restype = C.c_int
+    L.sblas_hip_debug_spmm_panel_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.sblas_hip_spmv_csr_f64_i32.restype = C.c_int
     L.sblas_hip_spmv_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, f64, f64, vp]
     L.sblas_hip_axpby_f64.restype = C.c_int
@@ -183,6 +185,13 @@ def spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, alpha, beta, Cmat, ld
         _dev_ptr(Bt, torch.float64, "Bt"), ldbt, n, alpha, beta,
         _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc)
     check(rc, "sblas_hip_spmm_csr_rowmajorB_f64_i32")
+
+
+def panel_stats(reset=True):
+    """(windowed, direct, fallback) panel counts of the SpMM launches since the last reset."""
+    out = (C.c_uint64 * 4)()
+    check(lib().sblas_hip_debug_spmm_panel_stats(out, 1 if reset else 0), "sblas_hip_debug_spmm_panel_stats")
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def spmv(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offset=0):

@@ -52,6 +52,16 @@ def oracle_spmm_ld(oracle, A, B_host, ldb, n, alpha, beta, C_host, ldc):
     return Cfull
 
 
+@pytest.fixture
+def variant_env():
+    old = os.environ.get("SBLAS_SPMM_VARIANT")
+    yield lambda v: os.environ.__setitem__("SBLAS_SPMM_VARIANT", v)
+    if old is None:
+        os.environ.pop("SBLAS_SPMM_VARIANT", None)
+    else:
+        os.environ["SBLAS_SPMM_VARIANT"] = old
+
+
 @pytest.fixture(scope="module")
 def env(sblas, oracle, cuda):
     import torch
@@ -95,10 +105,12 @@ def test_ash85_spmm_known_answers(env, ash85, key):
     assert oracle.lib().orc_check_equal(ref, got, got.size) == 1          # the reference's own criterion (1e-3 abs)
 
 
+@pytest.mark.parametrize("variant", ["auto", "dpp", "direct"])
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 130, 256])
-def test_spmm_every_column_count(env, n):
+def test_spmm_every_column_count(env, variant_env, variant, n):
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
+    variant_env(variant)
     rp, ci, v = synth.random_csr(150, 97, 9, seed=n, empty_every=11, long_row=(5, 333))
     A = Dev(torch, dev, rp, ci, v, 97)
     rng = np.random.default_rng(n)
@@ -129,6 +141,31 @@ def test_spmm_leading_dimensions_and_untouched_padding(env, n):
     assert (pad_got == C0.reshape(n, ldc)[:, M:]).all()
 
 
+def test_spmm_nonfinite_b_rows_not_referenced_stay_out(env, variant_env):
+    """Masked DPP slots must not touch real B rows: an Inf/NaN in a B row that no nonzero references must not
+    leak into C (0 * Inf = NaN); the reference's CPU loop never reads such rows."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, n = 300, 64
+    rp, ci, v = synth.banded(rows, 7, 40)            # 7 nonzeros per row: every sweep has masked slots
+    ci = ci.copy()
+    ci[ci == 0] = 1                                  # nobody references B row 0 ...
+    used = np.zeros(rows, bool)
+    used[ci] = True
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal(rows * n).reshape(n, rows)
+    B[:, ~used] = np.inf                             # ... nor these rows
+    B[:, 0] = np.nan
+    B = np.ascontiguousarray(B).reshape(-1)
+    C0 = rng.standard_normal(rows * n)
+    for variant in ("dpp", "win64", "auto"):
+        variant_env(variant)
+        got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
+        ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
+        assert np.isfinite(ref).all() and np.isfinite(got).all() and close(got, ref), variant
+
+
 def test_spmm_beta_zero_does_not_read_c(env):
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
@@ -141,8 +178,10 @@ def test_spmm_beta_zero_does_not_read_c(env):
     assert np.isfinite(got).all() and close(got, ref)
 
 
-def test_spmm_degenerate_shapes(env):
+@pytest.mark.parametrize("variant", ["auto", "dpp"])
+def test_spmm_degenerate_shapes(env, variant_env, variant):
     sblas, oracle, torch, dev = env
+    variant_env(variant)
     # nnz = 0: C = beta*C
     rp = np.zeros(11, np.int32)
     A = Dev(torch, dev, rp, np.zeros(0, np.int32), np.zeros(0), 6)
@@ -217,7 +256,7 @@ def test_method2_row_blocks_merge_and_epilogue(env, ash85, g):
     rp, ci, v = ash85["rowptr"], ash85["colidx"], ash85["val"]
     Bh = oracle.rand0to1(M * N)
     B = torch.from_numpy(Bh).to(dev)
-    ws = torch.empty(M * 64, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(M, M, 523, N) // 8, dtype=torch.float64, device=dev)
     total = torch.zeros(M * N, dtype=torch.float64, device=dev)
     for i in range(g):
         d = sblas.partition_nnz(rp, g, i)
@@ -291,7 +330,7 @@ def test_full_size_properties(env):
     rows, (rp, ci, v) = synth.nd24k_like()
     N = 64
     A = Dev(torch, dev, rp, ci, v, rows)
-    ws = torch.empty(rows * 64, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), N) // 8, dtype=torch.float64, device=dev)
 
     def run(Bt_, alpha=1.0, beta=0.0, C=None):
         C = torch.zeros(rows * N, dtype=torch.float64, device=dev) if C is None else C
@@ -329,17 +368,7 @@ def test_full_size_properties(env):
 # ---------------------------------------------------------------------------------------------------------
 # the windowed (row panel x LDS B tile) kernel and its per-panel fallback
 # ---------------------------------------------------------------------------------------------------------
-@pytest.fixture
-def variant_env():
-    old = os.environ.get("SBLAS_SPMM_VARIANT")
-    yield lambda v: os.environ.__setitem__("SBLAS_SPMM_VARIANT", v)
-    if old is None:
-        os.environ.pop("SBLAS_SPMM_VARIANT", None)
-    else:
-        os.environ["SBLAS_SPMM_VARIANT"] = old
-
-
-@pytest.mark.parametrize("variant", ["direct", "win32", "win64", "win128", "auto"])
+@pytest.mark.parametrize("variant", ["direct", "dpp", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
 @pytest.mark.parametrize("shape", [(1000, 40, 100, 64), (777, 60, 300, 130), (200, 30, 20, 64), (90, 80, 45, 256)])
 def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     """Banded, ascending rows: dense enough over their span that the windowed path is taken.  Covers several
@@ -357,7 +386,7 @@ def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     assert close(got, ref), (variant, shape, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["win32", "win64", "win128"])
+@pytest.mark.parametrize("variant", ["win32", "win64", "win128", "win64w64"])
 @pytest.mark.parametrize("damage", ["all_descending", "one_row_shuffled", "first_col_not_min", "duplicates"])
 def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, damage):
     """The windowed path expects ascending columns but must never depend on it: panels whose rows break the
@@ -394,7 +423,7 @@ def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, dama
     assert close(got, ref), (variant, damage, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["win32", "win64", "win128"])
+@pytest.mark.parametrize("variant", ["win32", "win64", "win128", "win64w64"])
 def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     """Dense-band panels next to sparse wide-span panels (direct path chosen per panel), empty rows, rows longer
     than several chunks, and a method-2 style row block (re-based row pointers, C offset, ldc > rows)."""
@@ -428,7 +457,7 @@ def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     Cbig = rng.standard_normal(rows * n)
     Bd = torch.from_numpy(B).to(dev)
     Cd = torch.from_numpy(Cbig.copy()).to(dev)
-    ws = torch.empty(K * 64, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(300, K, 1, n) // 8, dtype=torch.float64, device=dev)
     sblas.spmm(300, K, As.rowptr, As.colidx, As.val, Bd, K, n, 1.0, 1.0, Cd, rows, ws, c_offset=100)
     want = Cbig.copy().reshape(n, rows)
     part = np.zeros(300 * n)
