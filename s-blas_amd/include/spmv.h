@@ -1,0 +1,87 @@
+// spmv.h -- y = alpha * A * x + beta * y with A in CSR, on one or more MI355X (reference spmv.h:15-19, :35-39).
+//   sblas_spmv_csr_cpu  single-threaded host loop (the verifier)
+//   sblas_spmv_csr_v1   A split into nnz-balanced row blocks, x and y replicated; partial y merged by an RCCL
+//                       all-reduce, then y = beta*y + alpha*sum on every GPU
+#ifndef SBLAS_AMD_SPMV_H
+#define SBLAS_AMD_SPMV_H
+
+#include <assert.h>
+#include <iostream>
+#include <stdio.h>
+#include <vector>
+
+#include "matrix.h"
+#include "spmm.h"
+#include "utility.h"
+
+using namespace std;
+
+template <typename IdxType, typename DataType>
+void sblas_spmv_csr_cpu(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxType, DataType> *pB,
+                        DenseVector<IdxType, DataType> *pC, DataType alpha, DataType beta)
+{
+    assert((pA->width) == (pB->length));
+    assert((pA->height) == (pC->length)); // the reference asserts x and y the same length (square only, spmv.h:21)
+    for (size_t i = 0; i < (size_t)pA->height; ++i) {
+        DataType sum = 0;
+        for (IdxType j = pA->csrRowPtr[i]; j < pA->csrRowPtr[i + 1]; ++j)
+            sum += pA->csrVal[j] * pB->val[pA->csrColIdx[j]];
+        pC->val[i] = beta * pC->val[i] + alpha * sum;
+    }
+}
+
+// Preconditions: A.sync2gpu(g, segment); x, y .sync2gpu(g, replicate).  On return every y.val_gpu[i] holds the
+// result; refresh the host copy with y.sync2cpu(i).
+template <typename IdxType, typename DataType>
+void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxType, DataType> *pB,
+                       DenseVector<IdxType, DataType> *pC, DataType alpha, DataType beta, unsigned n_gpu)
+{
+    assert((pA->width == pB->length));
+    assert((pA->height) == (pC->length));
+    sblas_detail::require_f64_i32<IdxType, DataType>("SBLAS_SPMV_CSR_V1");
+    assert(pA->policy == segment && pB->policy == replicate && pC->policy == replicate);
+    const int64_t M = pA->height, K = pA->width;
+
+    std::vector<int> devs(n_gpu);
+    for (unsigned i = 0; i < n_gpu; ++i) devs[i] = sblas_rt::physical_device(i);
+    void *comm = NULL;
+    sblas_rt::must_sblas(sblas_hip_comm_get((int)n_gpu, devs.data(), &comm), "sblas_hip_comm_get");
+
+    std::vector<double *> ycopy(n_gpu, (double *)NULL);
+    std::vector<void *> streams(n_gpu);
+    std::vector<GPU_Timer *> timers(n_gpu);
+    for (unsigned i = 0; i < n_gpu; ++i) {
+        CUDA_SAFE_CALL(cudaSetDevice((int)i));
+        streams[i] = sblas_rt::stream(i);
+        SAFE_ALOC_GPU(ycopy[i], (size_t)M * sizeof(double));
+        CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(double), (hipStream_t)streams[i]));
+        const int64_t m_i = (int64_t)pA->get_gpu_row_ptr_num(i) - 1;
+        sblas_rt::must_sblas(
+            sblas_hip_spmv_csr_f64_i32(-1, streams[i], m_i, K, (int64_t)pA->nnz_gpu[i],
+                                       (const int32_t *)pA->csrRowPtr_gpu[i], (const int32_t *)pA->csrColIdx_gpu[i],
+                                       (const double *)pA->csrVal_gpu[i], (const double *)pB->val_gpu[i], 1.0, 1.0,
+                                       ycopy[i] + (size_t)pA->starting_row_gpu[i]),
+            "sblas_hip_spmv_csr_f64_i32");
+        timers[i] = new GPU_Timer((hipStream_t)streams[i]);
+        timers[i]->start_timer();
+    }
+    sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ycopy.data(), streams.data(), M),
+                         "sblas_hip_allreduce_sum_f64");
+    for (unsigned i = 0; i < n_gpu; ++i) {
+        CUDA_SAFE_CALL(cudaSetDevice((int)i));
+        timers[i]->stop_timer();
+        sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], M, (double)alpha, ycopy[i], (double)beta,
+                                                 (double *)pC->val_gpu[i]),
+                             "sblas_hip_axpby_f64");
+    }
+    sblas_rt::sync_all(n_gpu);
+    for (unsigned i = 0; i < n_gpu; ++i) {
+        CUDA_SAFE_CALL(cudaSetDevice((int)i));
+        cout << "GPU-" << i << " NCCL Time: " << timers[i]->measure() << " ms." << std::endl;
+        delete timers[i];
+        SAFE_FREE_GPU(ycopy[i]);
+    }
+    CUDA_CHECK_ERROR();
+}
+
+#endif
