@@ -28,6 +28,32 @@ sys.path.insert(0, os.path.join(ROOT, "s-blas_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
+# stage-2 kernel launched for a 64-column block under each SBLAS_SPMM_VARIANT (s-blas_amd/csrc/kernels.hip)
+KERNEL_OF_VARIANT = {"": "spmm_direct_dpp_kernel<true>", "auto": "spmm_direct_dpp_kernel<true>",
+                     "dpp": "spmm_direct_dpp_kernel<true>", "direct": "spmm_rowpanel_kernel",
+                     "win32": "spmm_window_kernel<2,64,8>", "win64": "spmm_window_kernel<4,128,4>",
+                     "win128": "spmm_window_kernel<8,128,4>", "win64w64": "spmm_window_kernel<4,64,8>",
+                     "win32w128": "spmm_window_kernel<2,128,4>"}
+
+
+def measured_traffic(kernel, rows, nnz, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r*_hbm_traffic.json; FETCH_SIZE and
+    WRITE_SIZE in separate passes, gfx950 read correction applied there).  PMC counters cannot be read from inside
+    this process, so the figure is only reported when the profile was taken on this very kernel and workload."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            w = d.get("workload", {})
+            if (w.get("rows"), w.get("nnz"), w.get("n")) != (rows, nnz, n):
+                continue
+            k = d["kernels"].get("sblas::" + kernel)
+            if k:
+                return k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
 
 def algorithmic_bytes(rows, cols, nnz, n, beta_nonzero=True):
     """nnz*(4+8) + (M+1)*4 + 8*K*N + (16 or 8)*M*N."""
@@ -85,6 +111,54 @@ def cpu_baseline(rows, cols, n, rp, ci, v, Bh, budget_s):
             "sample": sample, "seconds": round(dt, 2), "host_cpu": model, "host_threads_available": os.cpu_count()}
 
 
+def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp, ci, v):
+    """y = A*x + y on every rank (replicas: SpMV has no column dimension to split), HIP-event kernel time."""
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rowptr, colidx, val = d(rp), d(ci), d(v)
+    x = torch.ones(cols, dtype=torch.float64, device=dev)
+    y = torch.ones(rows, dtype=torch.float64, device=dev)
+    for _ in range(args.warmup):
+        S.spmv(rows, cols, rowptr, colidx, val, x, 1.0, 1.0, y)
+    torch.cuda.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        S.spmv(rows, cols, rowptr, colidx, val, x, 1.0, 1.0, y)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    t_k = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    alg = nnz * 12 + (rows + 1) * 4 + 8 * cols + 16 * rows
+    # y = 1 + steps_total * A*1  -> compare with row sums (exact structure check)
+    if rank == 0:
+        rs = np.add.reduceat(v, rp[:-1].astype(np.int64)) if nnz else np.zeros(rows)
+        want = 1.0 + (args.warmup + args.steps) * rs
+        if not np.allclose(y.cpu().numpy(), want, rtol=1e-9, atol=1e-9):
+            raise SystemExit("spmv bench result mismatch")
+        out = {"metric": "SpMV GFLOP/s (2*nnz/t), CSR fp64", "value": round(world * 2.0 * nnz * args.steps / elapsed / 1e9, 2),
+               "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
+               "config": {"workload": "SpMV y=A*x+y, %s, nnz=%d, replicas only" % (name, nnz), "rows": rows, "nnz": nnz},
+               "roofline": {"bound": "hbm", "kernel": "spmv_csr_kernel", "achieved": round(alg / t_k / 1e9, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4),
+                            "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_k * 1e3, 5)},
+               "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +169,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="row-count scale of the synthetic stand-in (rehearsal only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-method2", action="store_true")
+    ap.add_argument("--op", choices=["spmm", "spmv"], default="spmm",
+                    help="spmm (the headline metric) or spmv (same matrix, x = y0 = 1; secondary measurement)")
     args = ap.parse_args()
 
     import torch
@@ -121,6 +197,8 @@ def main():
             dist.barrier()
 
     name, rows, cols, nnz, rp, ci, v = load_workload(args)
+    if args.op == "spmv":
+        return bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp, ci, v)
     n = args.ncols
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rowptr, colidx, val = d(rp), d(ci), d(v)
@@ -179,6 +257,8 @@ def main():
     flops_step = 2.0 * nnz * n                      # per GPU
     value = world * flops_step * args.steps / elapsed / 1e9
     alg = algorithmic_bytes(rows, cols, nnz, n, True)
+    kernel = KERNEL_OF_VARIANT.get(os.environ.get("SBLAS_SPMM_VARIANT", ""), "spmm_direct_dpp_kernel<true>") if n > 32 and n <= 64 else "spmm (n=%d)" % n
+    traffic, traffic_src = measured_traffic(kernel, rows, nnz, n)
     out = {
         "metric": "SpMM GFLOP/s (2*nnz*N/t), CSR x dense N=64, fp64",
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,9 +267,10 @@ def main():
         "config": {"workload": "SpMM method-1 (dense-B column partition), %s, nnz=%d, N=%d columns per GPU, alpha=beta=1, "
                                "inputs resident in HBM; step = B->row-major staging + row-panel SpMM" % (name, nnz, n),
                    "rows": rows, "cols": cols, "nnz": nnz, "n_cols_per_gpu": n, "parallelism": "method1-colblock x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "spmm_rowpanel_kernel",
+        "roofline": {"bound": "hbm", "kernel": kernel,
                      "achieved": round(alg / t_stage2 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg / t_stage2 / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(alg / t_stage2 / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_stage2 * 1e3, 5),
                      "staging_kernel_ms": round(t_stage1 * 1e3, 5),
                      "kernel_gflops": round(flops_step / t_stage2 / 1e9, 1)},
