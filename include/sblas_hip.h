@@ -80,6 +80,9 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
  * took the LDS-windowed path [0], the direct path because they are too sparse over their column span [1], or were
  * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2].  out[3] = 0. */
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
+/* Diagnostics: per-phase shader-cycle sums written by the windowed kernel when SBLAS_ABLATE has bit 2 set
+ * (a diagnostic mode; see g_prof in kernels.hip for the slots). */
+int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset);
 
 /* ---------------------------------------------------------------------------------------
  * SpMV:  y = alpha * A * x + beta * y

@@ -37,6 +37,8 @@ inline int spmm_variant()
     if (!e || !*e) return sblas::SPMM_VARIANT_AUTO;
     if (!strcmp(e, "direct")) return sblas::SPMM_VARIANT_DIRECT;
     if (!strcmp(e, "dpp")) return sblas::SPMM_VARIANT_DIRECT_DPP;
+    if (!strcmp(e, "win2")) return sblas::SPMM_VARIANT_WINDOW2;
+    if (!strcmp(e, "win3")) return sblas::SPMM_VARIANT_WINDOW3;
     if (!strcmp(e, "win32")) return sblas::SPMM_VARIANT_WINDOW_R32;
     if (!strcmp(e, "win64")) return sblas::SPMM_VARIANT_WINDOW_R64;
     if (!strcmp(e, "win128")) return sblas::SPMM_VARIANT_WINDOW_R128;
@@ -94,11 +96,13 @@ int64_t sblas_hip_spmm_ldbt(int64_t n)
 
 size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
 {
-    (void)rows;
     (void)nnz;
     if (cols <= 0 || n <= 0) return 0;
-    // one extra, all-zero row: the target of masked DPP slots in the kernels
-    return ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
+    // Bt plus one extra all-zero row (the target of masked DPP slots), then one int2 per 48-row panel (the
+    // panel classifier's verdicts)
+    const size_t bt = ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
+    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_WINDOW2_PANEL_ROWS - 1) / sblas::SPMM_WINDOW2_PANEL_ROWS;
+    return bt + panels * 8 + 16;
 }
 
 int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n, const double *B,
@@ -129,7 +133,7 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID; // 16-byte tile loads
-    return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, (int)cols, rowptr, colidx, val, Bt, ldbt,
+    return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, val, Bt, ldbt,
                                        (int)n, alpha, beta, C, ldc, spmm_variant()) == hipSuccess
                ? SBLAS_OK
                : SBLAS_E_HIP;
@@ -152,6 +156,15 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (rc != SBLAS_OK) return rc;
     return sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n,
                                                 alpha, beta, C, ldc);
+}
+
+int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset)
+{
+    if (!out) return SBLAS_E_INVALID;
+    unsigned long long tmp[16];
+    if (sblas::prof_stats(tmp, reset != 0) != hipSuccess) return SBLAS_E_HIP;
+    for (int i = 0; i < 16; ++i) out[i] = tmp[i];
+    return SBLAS_OK;
 }
 
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset)

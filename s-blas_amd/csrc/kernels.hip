@@ -12,6 +12,7 @@
 // 64-wide wavefronts; there is no 32-lane code path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace sblas {
@@ -180,6 +181,16 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_rowpanel_kernel(
 // panel census of the windowed kernel: [0] windowed, [1] direct (too sparse over its span), [2] windowed but
 // recomputed by the fallback.  One atomic per panel; read through sblas_hip_debug_spmm_panel_stats.
 __device__ unsigned long long g_panel_stats[4];
+// cycle stamps of the diagnostic mode (SBLAS_ABLATE bit 2): [0] consumer prologue, [1] consumer visits,
+// [2] consumer barrier waits, [3] consumer epilogue, [4] loader put, [5] loader fetch issue, [6] loader barrier
+// waits, [7] samples (consumer waves), [8] samples (loader waves), [9] whole kernel per wave
+__device__ unsigned long long g_prof[16];
+__device__ __forceinline__ unsigned long long stamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
 
 constexpr int WIN_THREADS = 1024;
 // two B tiles + one all-zero Bt row (target of masked DPP slots) + a few ints
@@ -214,11 +225,54 @@ constexpr size_t win_lds_bytes(int W) { return (2 * (size_t)W * 64 + 64) * sizeo
                  : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
                  : "memory")
 
+// Eight nonzeros at DPP slots K0..K0+7, fully pipelined: all eight LDS reads are in flight before the first
+// FMA, and the FMAs alternate between two accumulators so that the fp64 dependency chain is half as long.
+// The two address temporaries are recycled: a ds_read has consumed its address operand once it has issued.
+#define SBLAS_DPP8(K0, K1, K2, K3, K4, K5, K6, K7)                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp %[a0], %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a1], %[co], %[lb] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "ds_read_b64 %[d0], %[a0]\n\t"                                                                      \
+                 "ds_read_b64 %[d1], %[a1]\n\t"                                                                      \
+                 "v_add_u32_dpp %[a0], %[co], %[lb] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a1], %[co], %[lb] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "ds_read_b64 %[d2], %[a0]\n\t"                                                                      \
+                 "ds_read_b64 %[d3], %[a1]\n\t"                                                                      \
+                 "v_add_u32_dpp %[a0], %[co], %[lb] row_newbcast:" #K4 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a1], %[co], %[lb] row_newbcast:" #K5 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "ds_read_b64 %[d4], %[a0]\n\t"                                                                      \
+                 "ds_read_b64 %[d5], %[a1]\n\t"                                                                      \
+                 "v_add_u32_dpp %[a0], %[co], %[lb] row_newbcast:" #K6 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "v_add_u32_dpp %[a1], %[co], %[lb] row_newbcast:" #K7 " row_mask:0xf bank_mask:0xf\n\t"             \
+                 "ds_read_b64 %[d6], %[a0]\n\t"                                                                      \
+                 "ds_read_b64 %[d7], %[a1]\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(7)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[d0] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(6)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[d1] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(5)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[d2] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(4)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[d3] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[d4] row_newbcast:" #K4 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[d5] row_newbcast:" #K5 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], %[d6] row_newbcast:" #K6 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c1], %[gv], %[d7] row_newbcast:" #K7 " row_mask:0xf bank_mask:0xf\n\t"            \
+                 : [c0] "+v"(acc), [c1] "+v"(acc_b), [a0] "=&v"(a0), [a1] "=&v"(a1), [d0] "=&v"(d0), [d1] "=&v"(d1), \
+                   [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4), [d5] "=&v"(d5), [d6] "=&v"(d6), [d7] "=&v"(d7)    \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory")
+
 // Consume nonzeros [g0, g0+ng) (ng <= 16) of a 64-wide register chunk against the LDS tile whose first Bt row
 // is tile_lo.  The segment is first copied into slots 0..ng-1 of every 16-lane DPP row (ds_bpermute, no LDS
 // traffic); slots >= ng get value 0 and the address of the all-zero row, so they add exactly 0.
-__device__ __forceinline__ void consume_dpp16(double &acc, int cj, double vj, int g0, int ng, int tile_lo,
-                                              unsigned lb, unsigned zero_rel, int lane)
+// acc / acc_b: even / odd slots (the caller adds them once per row).
+__device__ __forceinline__ void consume_dpp16(double &acc, double &acc_b, int cj, double vj, int g0, int ng,
+                                              int tile_lo, unsigned lb, unsigned zero_rel, int lane)
 {
     const int sub = lane & 15;
     const int src = (g0 + sub) << 2;
@@ -229,17 +283,20 @@ __device__ __forceinline__ void consume_dpp16(double &acc, int cj, double vj, in
     const unsigned co = on ? ((unsigned)(gc - tile_lo) << 9) : zero_rel;
     const double gv = on ? __hiloint2double(hi, lo) : 0.0;
     unsigned a0, a1, a2, a3;
-    double d0, d1, d2, d3;
-    SBLAS_DPP4(0, 1, 2, 3);
+    double d0, d1, d2, d3, d4, d5, d6, d7;
     if (ng > 4) {
-        SBLAS_DPP4(4, 5, 6, 7);
+        SBLAS_DPP8(0, 1, 2, 3, 4, 5, 6, 7);
         if (ng > 8) {
-            SBLAS_DPP4(8, 9, 10, 11);
-            if (ng > 12) SBLAS_DPP4(12, 13, 14, 15);
+            if (ng > 12) {
+                SBLAS_DPP8(8, 9, 10, 11, 12, 13, 14, 15);
+            } else {
+                SBLAS_DPP4(8, 9, 10, 11);
+            }
         }
+    } else {
+        SBLAS_DPP4(0, 1, 2, 3);
     }
 }
-
 
 __device__ __forceinline__ void load_chunk(const int *__restrict__ colidx, const double *__restrict__ val, int p,
                                            int pend, int lane, int &c, double &v)
@@ -423,10 +480,10 @@ __global__ __launch_bounds__(WIN_THREADS, MIN_WAVES) void spmm_window_kernel(
                         break;
                     }
                     const int k_end = pos[r] + take;
-                    double a_acc = acc[r];
+                    double a_acc = acc[r], b_acc = 0.0;
                     for (int g0 = pos[r]; g0 < k_end; g0 += 16)
-                        consume_dpp16(a_acc, cj[r], vj[r], g0, min(16, k_end - g0), tile_lo, lb, zero_rel, lane);
-                    acc[r] = a_acc;
+                        consume_dpp16(a_acc, b_acc, cj[r], vj[r], g0, min(16, k_end - g0), tile_lo, lb, zero_rel, lane);
+                    acc[r] = a_acc + b_acc;
                     pos[r] = k_end;
                     if (k_end < cnt) break; // chunk not exhausted: the rest is for later tiles
                 }
@@ -464,6 +521,607 @@ __global__ __launch_bounds__(WIN_THREADS, MIN_WAVES) void spmm_window_kernel(
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
             const double s = alpha * ctile[j * (R + 1) + r];
             *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form, second generation: loader / consumer wave specialisation.
+//
+// The first windowed kernel lets every wave fetch its share of the next B tile AND stream its rows'
+// (col,val) chunks; because vmcnt retires in order and hipcc waits vmcnt(0) at each use, every (row,tile)
+// visit stalls on the tile prefetch issued a moment earlier (SQ_WAIT_ANY 58 %).  Here the roles are split:
+//   waves 12..15 (loaders)   own ALL Bt traffic: tile t+1 -> registers -> the idle LDS buffer while the
+//                            consumers work on tile t; they do nothing else;
+//   waves 0..11 (consumers)  load the nonzeros of their RPW rows ONCE per panel into registers
+//                            (CH chunks of 64 per row; rows longer than 64*CH send the panel to the direct
+//                            kernel), check that each row's columns ascend, and then run the tile loop with
+//                            LDS reads and DPP math only -- no global load, no vmcnt wait.
+// One workgroup barrier per tile.  Which panels qualify is decided by classify_panels_kernel (below); the
+// direct DPP kernel skips those panels and handles the rest, so any matrix is covered by the pair.
+// ---------------------------------------------------------------------------------------------
+constexpr int W2_ROWS = 128;              // Bt rows per LDS tile
+constexpr int W2_TILE = W2_ROWS * 64;     // doubles
+constexpr int W2_NCONS = 12; // consumer waves; the remaining 4 of the 16 waves are loaders
+constexpr int W2_RPW = 4;
+constexpr int W2_PANEL = W2_NCONS * W2_RPW; // 48 rows
+constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64 * sizeof(int);
+
+// info[p] = (cmin, cmax) of panel p when it should take the windowed path, (1, 0) otherwise.
+// One wave per panel, one lane per row.
+__global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
+                                                             const int *__restrict__ rowptr,
+                                                             const int *__restrict__ colidx, int max_row_len,
+                                                             float min_density, int2 *__restrict__ info)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npanels) return;
+    const int row = p * panel_rows + lane;
+    int first = 0x7fffffff, last = -1, len = 0;
+    if (lane < panel_rows && row < rows) {
+        const int a = rowptr[row], b = rowptr[row + 1];
+        len = b - a;
+        if (len > 0) {
+            first = colidx[a];
+            last = colidx[b - 1];
+        }
+    }
+    int nnz = len, mlen = len;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        first = min(first, __shfl_xor(first, m, WAVE));
+        last = max(last, __shfl_xor(last, m, WAVE));
+        nnz += __shfl_xor(nnz, m, WAVE);
+        mlen = max(mlen, __shfl_xor(mlen, m, WAVE));
+    }
+    if (lane == 0) {
+        const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len &&
+                        (float)nnz >= min_density * (float)(last - first + 1);
+        info[p] = ok ? make_int2(first, last) : make_int2(1, 0);
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void spmm_window2_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int ablate)
+{
+    constexpr int RPW = W2_RPW, R = W2_PANEL;
+    static_assert(64 * (R + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zero_row = smem + 2 * W2_TILE;
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    const int2 span = info[panel];
+    if (span.x > span.y) return; // not a windowed panel: the direct kernel owns it (whole workgroup leaves)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * R;
+    const int col0 = blockIdx.y * 64;
+    const unsigned ld32 = (unsigned)ldbt;
+    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const bool loader = wave >= W2_NCONS;
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    double acc[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) acc[r] = 0.0;
+
+    if (loader) {
+        // ---------------- loader waves: 256 threads move one 64 KiB tile = 16 x 16 B each ----------------
+        const int ltid = tid - W2_NCONS * 64;
+        double2 st[16];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                const int brow = t * W2_ROWS + (q >> 5);
+                double2 x = make_double2(0.0, 0.0);
+                if (brow < cols)
+                    x = *reinterpret_cast<const double2 *>(Bt + (size_t)((unsigned)brow * ld32) + col0 + ((q & 31) << 1));
+                st[i] = x;
+            }
+        };
+        auto put = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                *reinterpret_cast<double2 *>(smem + buf * W2_TILE + (q << 1)) = st[i];
+            }
+        };
+        const bool prof = (ablate & 4) != 0;
+        unsigned long long T0 = 0, tput = 0, tfetch = 0, tbar = 0, ta = 0, tb = 0;
+        if (prof) T0 = stamp();
+        fetch(t_lo);
+        put(0);
+        if (t_lo < t_hi) fetch(t_lo + 1); // stays in flight across the barrier
+        __syncthreads(); // P: tile t_lo is in LDS, the consumers' rows are in registers and validated
+        if (sm_i[0] == 0) {
+            for (int t = t_lo; t <= t_hi; ++t) {
+                if (prof) ta = stamp();
+                if (t < t_hi) {
+                    // registers hold tile t+1 (fetched one iteration ago): park it in the buffer the consumers
+                    // left at the previous barrier, then start fetching tile t+2 so that its L2 latency spans the
+                    // consumers' whole next iteration
+                    put(((t - t_lo) & 1) ^ 1);
+                    if (prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tb = stamp(); tput += tb - ta; }
+                    if (t + 1 < t_hi) fetch(t + 2);
+                    if (prof) { ta = stamp(); tfetch += ta - tb; }
+                }
+                if (!(ablate & 1)) __syncthreads(); // E_t
+                if (prof) { tb = stamp(); tbar += tb - ta; }
+            }
+        }
+        if (prof && lane == 0) {
+            atomicAdd(&g_prof[4], tput);
+            atomicAdd(&g_prof[5], tfetch);
+            atomicAdd(&g_prof[6], tbar);
+            atomicAdd(&g_prof[8], 1ull);
+            atomicAdd(&g_prof[9], stamp() - T0);
+        }
+        __syncthreads(); // V
+    } else {
+        // ---------------- consumer waves ----------------
+        const bool prof = (ablate & 4) != 0;
+        unsigned long long T0 = 0, tvis = 0, tbar = 0, ta = 0, tb = 0;
+        if (prof) T0 = stamp();
+        int p0[RPW], len[RPW];
+        int cc[RPW];            // current chunk (columns / values), the one being consumed
+        double cv[RPW];
+        int sc[RPW][CH > 1 ? CH - 1 : 1]; // chunks 1..CH-1, waiting their turn
+        double sv[RPW][CH > 1 ? CH - 1 : 1];
+        int bad = 0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = row0 + wave * RPW + r;
+            p0[r] = 0;
+            len[r] = 0;
+            if (row < rows) {
+                p0[r] = wave_uniform(rowptr[row]);
+                len[r] = wave_uniform(rowptr[row + 1]) - p0[r];
+            }
+        }
+        // every nonzero of my rows, issued back to back (one long burst per panel, then no global loads)
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            load_chunk(colidx, val, p0[r], p0[r] + len[r], lane, cc[r], cv[r]);
+#pragma unroll
+            for (int q = 1; q < CH; ++q)
+                load_chunk(colidx, val, p0[r] + 64 * q, p0[r] + len[r], lane, sc[r][q - 1], sv[r][q - 1]);
+        }
+        // Nothing above is waited for here: chunk 0 is needed first (the compiler waits for exactly those two
+        // loads), the stored chunks land while the first tiles are being processed.  Each chunk is checked for
+        // ascending columns (equal neighbours allowed; lanes past the end hold INT_MAX) when it becomes current.
+        auto chunk_ok = [&](int c, int cnt, int prev_last) -> bool {
+            const int prev = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, c);
+            return __ballot(lane > 0 && lane < cnt && c < prev) == 0ull && __builtin_amdgcn_readlane(c, 0) >= prev_last;
+        };
+        int last_col[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int cnt = min(64, len[r]);
+            last_col[r] = -1;
+            if (cnt > 0) {
+                if (!chunk_ok(cc[r], cnt, -1)) bad = 1;
+                last_col[r] = __builtin_amdgcn_readlane(cc[r], cnt - 1);
+            }
+        }
+        if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+        __syncthreads(); // P
+        if (prof && lane == 0) atomicAdd(&g_prof[0], stamp() - T0);
+        if (sm_i[0] == 0) {
+            int qcur[RPW], pos[RPW];
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) qcur[r] = 0, pos[r] = 0;
+            for (int t = t_lo; t <= t_hi; ++t) {
+                if (prof) ta = stamp();
+                const int cur = (t - t_lo) & 1;
+                const int tile_lo = t * W2_ROWS, tile_hi = tile_lo + W2_ROWS;
+                const unsigned tile_base = (unsigned)(uintptr_t)(smem + cur * W2_TILE);
+                const unsigned lb = tile_base + (unsigned)lane * 8u;
+                const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    for (;;) {
+                        const int cnt = min(64, len[r] - 64 * qcur[r]);
+                        if (cnt <= 0) break; // row finished
+                        const int take = __popcll(__ballot(lane >= pos[r] && lane < cnt && cc[r] < tile_hi));
+                        if (take == 0) break; // next nonzero belongs to a later tile
+                        const int k_end = pos[r] + take;
+                        double a_acc = acc[r], b_acc = 0.0;
+                        if (!(ablate & 2)) {
+                            for (int g0 = pos[r]; g0 < k_end; g0 += 16)
+                                consume_dpp16(a_acc, b_acc, cc[r], cv[r], g0, min(16, k_end - g0), tile_lo, lb,
+                                              zero_rel, lane);
+                        }
+                        acc[r] = a_acc + b_acc;
+                        pos[r] = k_end;
+                        if (k_end < cnt) break;
+                        // chunk exhausted: bring the next stored chunk forward (rare: once per 64 nonzeros)
+                        qcur[r] += 1;
+                        pos[r] = 0;
+#pragma unroll
+                        for (int q = 1; q < CH; ++q)
+                            if (qcur[r] == q) {
+                                cc[r] = sc[r][q - 1];
+                                cv[r] = sv[r][q - 1];
+                            }
+                        const int ncnt = min(64, len[r] - 64 * qcur[r]);
+                        if (ncnt > 0) {
+                            if (!chunk_ok(cc[r], ncnt, last_col[r])) bad = 1;
+                            last_col[r] = __builtin_amdgcn_readlane(cc[r], ncnt - 1);
+                        }
+                    }
+                }
+                if (prof) { tb = stamp(); tvis += tb - ta; }
+                if (!(ablate & 1)) __syncthreads(); // E_t
+                if (prof) { ta = stamp(); tbar += ta - tb; }
+            }
+            if (prof && lane == 0) {
+                atomicAdd(&g_prof[1], tvis);
+                atomicAdd(&g_prof[2], tbar);
+                atomicAdd(&g_prof[7], 1ull);
+                atomicAdd(&g_prof[9], stamp() - T0);
+            }
+            // every nonzero must have been consumed; a late chunk may have failed its order check
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                if (64 * qcur[r] + pos[r] < len[r]) bad = 1;
+            if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+        }
+        __syncthreads(); // V: verdict of the whole panel
+        if (sm_i[0] != 0) {
+            // a row of this panel is not in ascending column order: recompute the panel straight from L2
+            const unsigned lane_off = (unsigned)(col0 + lane);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                acc[r] = row_direct(colidx, val, Bt, ld32, lane_off, lane, p0[r], p0[r] + len[r]);
+        }
+    }
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[sm_i[0] == 0 ? 0 : 2], 1ull);
+
+    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows
+    double *ctile = smem;
+    if (!loader) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) ctile[lane * (R + 1) + wave * RPW + r] = acc[r];
+    }
+    __syncthreads(); // F
+    const int nrows = min(R, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * R; idx += 1024) {
+        const int r = idx % R, j = idx / R;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (R + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form, third generation ("quad" consumer).
+//
+// Cycle stamps on the second generation showed the tile loop bound by VALU issue: ~5 vector instructions per
+// nonzero (alignment, masks, one address add and one FMA per nonzero) at ~4 cycles each.  Here a consumer wave
+// handles FOUR nonzeros per step, one per 16-lane DPP row, each lane owning four columns of the 64-column tile:
+//     addr   = row_newbcast:k(co) + lane_base                 1 v_add_u32_dpp   (four different Bt rows at once)
+//     d0, d1 = LDS[addr], LDS[addr + 256]                     2 ds_read_b128    (conflict-free: 16 lanes x 16 B)
+//     acc0..3 += row_newbcast:k(val) * d                      4 v_fmac_f64_dpp
+// i.e. 1.25 vector instructions per nonzero.  The register window of a row is stored in "quad order" (lane
+// 16q+k holds entry 4k+q) and is kept LEFT-ALIGNED: after a visit has consumed `take` entries the window is
+// shifted by `take` with ds_bpermute -- issued after the math, so its latency is hidden behind the other rows --
+// and every visit starts at step 0 with the simple mask "entry < take".  The four DPP rows of a lane column
+// hold partial sums over different nonzeros and are folded once per row at the end of the panel.
+// Loader waves, tile protocol, classifier and fallback are those of the second generation.
+// ---------------------------------------------------------------------------------------------
+constexpr int W3_RPW = 3;
+constexpr int W3_PANEL = W2_NCONS * W3_RPW; // 36 rows
+
+// two steps (eight nonzeros), reads of both in flight before the first FMA; v110..v127 are scratch owned by
+// the statement (named literally because the two halves of a 128-bit destination must be addressed separately)
+#define SBLAS_QSTEP2(K0, K1)                                                                                         \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp v110, %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"              \
+                 "v_add_u32_dpp v111, %[co], %[lb] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"              \
+                 "s_nop 0\n\t"                                                                                       \
+                 "ds_read_b128 v[112:115], v110\n\t"                                                                 \
+                 "ds_read_b128 v[116:119], v110 offset:256\n\t"                                                      \
+                 "ds_read_b128 v[120:123], v111\n\t"                                                                 \
+                 "ds_read_b128 v[124:127], v111 offset:256\n\t"                                                      \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[112:113] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[114:115] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[116:117] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[118:119] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[120:121] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[122:123] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[124:125] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[126:127] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 : [c0] "+v"(q0), [c1] "+v"(q1), [c2] "+v"(q2), [c3] "+v"(q3)                                        \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", \
+                   "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+
+#define SBLAS_QSTEP1(K0)                                                                                             \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp v110, %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"              \
+                 "s_nop 0\n\t"                                                                                       \
+                 "ds_read_b128 v[112:115], v110\n\t"                                                                 \
+                 "ds_read_b128 v[116:119], v110 offset:256\n\t"                                                      \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[112:113] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[114:115] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[116:117] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[118:119] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 : [c0] "+v"(q0), [c1] "+v"(q1), [c2] "+v"(q2), [c3] "+v"(q3)                                        \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory", "v110", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119")
+
+// steps come in pairs; a pair whose second step lies past the end runs it on masked slots (value 0, zero row)
+#define SBLAS_QPAIR(K0, K1)                                                                                          \
+    if (npairs > (K0 / 2)) {                                                                                         \
+        SBLAS_QSTEP2(K0, K1);                                                                                        \
+    }
+
+// chunk of 64 nonzeros in quad order: lane 16q+k holds entry 4k+q
+__device__ __forceinline__ void load_chunk_quad(const int *__restrict__ colidx, const double *__restrict__ val, int p,
+                                                int pend, int eidx, int &c, double &v)
+{
+    const int idx = p + eidx;
+    c = 0x7fffffff;
+    v = 0.0;
+    if (idx < pend) {
+        c = colidx[idx];
+        v = val[idx];
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void spmm_window3_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int ablate)
+{
+    constexpr int RPW = W3_RPW, R = W3_PANEL;
+    static_assert(64 * (R + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zero_row = smem + 2 * W2_TILE;
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    const int2 span = info[panel];
+    if (span.x > span.y) return; // the direct kernel owns this panel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * R;
+    const int col0 = blockIdx.y * 64;
+    const unsigned ld32 = (unsigned)ldbt;
+    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const bool loader = wave >= W2_NCONS;
+    (void)ablate;
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    double acc[RPW][4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.0;
+    double dacc[RPW]; // only used by the fallback (one column per lane)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) dacc[r] = 0.0;
+
+    if (loader) {
+        const int ltid = tid - W2_NCONS * 64;
+        double2 st[16];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                const int brow = t * W2_ROWS + (q >> 5);
+                double2 x = make_double2(0.0, 0.0);
+                if (brow < cols)
+                    x = *reinterpret_cast<const double2 *>(Bt + (size_t)((unsigned)brow * ld32) + col0 + ((q & 31) << 1));
+                st[i] = x;
+            }
+        };
+        auto put = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                *reinterpret_cast<double2 *>(smem + buf * W2_TILE + (q << 1)) = st[i];
+            }
+        };
+        fetch(t_lo);
+        put(0);
+        if (t_lo < t_hi) fetch(t_lo + 1);
+        __syncthreads(); // P
+        for (int t = t_lo; t <= t_hi; ++t) {
+            if (t < t_hi) {
+                put(((t - t_lo) & 1) ^ 1);
+                if (t + 1 < t_hi) fetch(t + 2);
+            }
+            __syncthreads(); // E_t
+        }
+        __syncthreads(); // V
+    } else {
+        const int eidx = ((lane & 15) << 2) + (lane >> 4); // entry held by this lane inside a chunk / window
+        int p0[RPW], len[RPW];
+        int wc[RPW];           // current window: columns / values, quad order, left-aligned
+        double wv[RPW];
+        int sc[RPW][CH > 1 ? CH - 1 : 1];
+        double sv[RPW][CH > 1 ? CH - 1 : 1];
+        int wcnt[RPW], qcur[RPW], last_col[RPW];
+        int bad = 0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = row0 + wave * RPW + r;
+            p0[r] = 0;
+            len[r] = 0;
+            if (row < rows) {
+                p0[r] = wave_uniform(rowptr[row]);
+                len[r] = wave_uniform(rowptr[row + 1]) - p0[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            load_chunk_quad(colidx, val, p0[r], p0[r] + len[r], eidx, wc[r], wv[r]);
+#pragma unroll
+            for (int q = 1; q < CH; ++q)
+                load_chunk_quad(colidx, val, p0[r] + 64 * q, p0[r] + len[r], eidx, sc[r][q - 1], sv[r][q - 1]);
+        }
+        // ascending-column check of a chunk in quad order: the predecessor of entry e sits one DPP row up
+        // (or, for the first DPP row, in the last DPP row one slot to the left)
+        const int pred_lane = (lane >= 16) ? lane - 16 : lane + 47;
+        auto chunk_ok = [&](int c, int cnt, int prev_last) -> bool {
+            const int prev = __builtin_amdgcn_ds_bpermute(pred_lane << 2, c);
+            return __ballot(eidx > 0 && eidx < cnt && c < prev) == 0ull && __builtin_amdgcn_readlane(c, 0) >= prev_last;
+        };
+        auto lane_of_entry = [](int e) { return ((e & 3) << 4) + (e >> 2); };
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            wcnt[r] = min(64, len[r]);
+            qcur[r] = 0;
+            last_col[r] = -1;
+            if (wcnt[r] > 0) {
+                if (!chunk_ok(wc[r], wcnt[r], -1)) bad = 1;
+                last_col[r] = __builtin_amdgcn_readlane(wc[r], lane_of_entry(wcnt[r] - 1));
+            }
+        }
+        __syncthreads(); // P
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int cur = (t - t_lo) & 1;
+            const int tile_lo = t * W2_ROWS, tile_hi = tile_lo + W2_ROWS;
+            const unsigned tile_base = (unsigned)(uintptr_t)(smem + cur * W2_TILE);
+            const unsigned lb = tile_base + (unsigned)(lane & 15) * 16u;
+            const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                for (;;) {
+                    if (wcnt[r] == 0) {
+                        // window empty: next stored chunk, if the row has one
+                        if (64 * (qcur[r] + 1) >= len[r]) break;
+                        qcur[r] += 1;
+#pragma unroll
+                        for (int q = 1; q < CH; ++q)
+                            if (qcur[r] == q) {
+                                wc[r] = sc[r][q - 1];
+                                wv[r] = sv[r][q - 1];
+                            }
+                        wcnt[r] = min(64, len[r] - 64 * qcur[r]);
+                        if (!chunk_ok(wc[r], wcnt[r], last_col[r])) bad = 1;
+                        last_col[r] = __builtin_amdgcn_readlane(wc[r], lane_of_entry(wcnt[r] - 1));
+                    }
+                    // window is sorted and left-aligned: the entries of this tile are its first `take`
+                    const int take = wave_uniform((int)__popcll(__ballot(eidx < wcnt[r] && wc[r] < tile_hi)));
+                    if (take == 0) break;
+                    {
+                        const bool on = eidx < take;
+                        const unsigned co = on ? ((unsigned)(wc[r] - tile_lo) << 9) : zero_rel;
+                        const double gv = on ? wv[r] : 0.0;
+                        const int npairs = (take + 7) >> 3; // pairs of 4-nonzero steps
+                        double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
+                        SBLAS_QPAIR(0, 1)
+                        SBLAS_QPAIR(2, 3)
+                        SBLAS_QPAIR(4, 5)
+                        SBLAS_QPAIR(6, 7)
+                        SBLAS_QPAIR(8, 9)
+                        SBLAS_QPAIR(10, 11)
+                        SBLAS_QPAIR(12, 13)
+                        SBLAS_QPAIR(14, 15)
+                        acc[r][0] = q0;
+                        acc[r][1] = q1;
+                        acc[r][2] = q2;
+                        acc[r][3] = q3;
+                    }
+                    // slide the window: entry e of the new window is entry e+take of the old one
+                    const int rest = wcnt[r] - take;
+                    if (rest > 0) {
+                        const int se = eidx + take;
+                        const int src = lane_of_entry(se & 63) << 2;
+                        // lanes >= rest receive stale entries; every use of the window is masked by wcnt, so they
+                        // are never looked at -- and with no select here the shuffle is not waited for until the
+                        // next visit of this row
+                        const int nc = __builtin_amdgcn_ds_bpermute(src, wc[r]);
+                        const int nlo = __builtin_amdgcn_ds_bpermute(src, __double2loint(wv[r]));
+                        const int nhi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(wv[r]));
+                        wc[r] = nc;
+                        wv[r] = __hiloint2double(nhi, nlo);
+                    }
+                    wcnt[r] = rest;
+                    if (rest > 0) break; // what is left belongs to later tiles
+                }
+            }
+            __syncthreads(); // E_t
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            if (wcnt[r] != 0 || 64 * (qcur[r] + 1) < len[r]) bad = 1; // unconsumed nonzeros
+        if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+        __syncthreads(); // V
+        if (sm_i[0] != 0) {
+            const unsigned lane_off = (unsigned)(col0 + lane);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                dacc[r] = row_direct(colidx, val, Bt, ld32, lane_off, lane, p0[r], p0[r] + len[r]);
+        } else {
+            // fold the four DPP rows (partial sums over different nonzeros of the same row)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double x = acc[r][j];
+                    x += __shfl_xor(x, 16, WAVE);
+                    x += __shfl_xor(x, 32, WAVE);
+                    acc[r][j] = x;
+                }
+        }
+    }
+    const bool fell_back = sm_i[0] != 0;
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
+
+    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows
+    double *ctile = smem;
+    if (!loader) {
+        if (fell_back) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) ctile[lane * (R + 1) + wave * RPW + r] = dacc[r];
+        } else if (lane < 16) {
+            const int jj = lane;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int rr = wave * RPW + r;
+                ctile[(2 * jj) * (R + 1) + rr] = acc[r][0];
+                ctile[(2 * jj + 1) * (R + 1) + rr] = acc[r][1];
+                ctile[(32 + 2 * jj) * (R + 1) + rr] = acc[r][2];
+                ctile[(33 + 2 * jj) * (R + 1) + rr] = acc[r][3];
+            }
+        }
+    }
+    __syncthreads(); // F
+    const int nrows = min(R, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * R; idx += 1024) {
+        const int r = idx % R, j = idx / R;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (R + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
         }
     }
 }
@@ -510,7 +1168,7 @@ template <bool HALF>
 __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc)
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows)
 {
     constexpr int TILE_COLS = HALF ? 64 : 128;
     constexpr int PER_STEP = HALF ? 32 : 16; // nonzeros handled by one 16-slot sweep
@@ -520,6 +1178,13 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int row0 = xcd_contiguous_panel(blockIdx.x, npanels) * WIDE_PANEL;
     const int col0 = blockIdx.y * TILE_COLS;
     const int row = row0 + wave;
+    // rows of panels that the windowed kernel owns are skipped (wave-uniform: one row per wave)
+    bool mine = row < rows;
+    if (info && mine) {
+        const int2 span = info[row / info_panel_rows];
+        mine = span.x > span.y;
+        if (mine && lane == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
+    }
     const int sub = lane & 15;
     const int half = HALF ? (lane >> 5) : 0;
     const unsigned ldb8 = (unsigned)ldbt * 8u;                                       // bytes per Bt row
@@ -528,7 +1193,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
 
     double acc0 = 0.0, acc1 = 0.0;
-    if (row < rows) {
+    if (mine) {
         const int p0 = wave_uniform(rowptr[row]);
         const int p1 = wave_uniform(rowptr[row + 1]);
         for (int p = p0; p < p1; p += WAVE) {
@@ -586,6 +1251,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
         acc0 += __shfl_xor(acc0, 32, WAVE);
         acc1 += __shfl_xor(acc1, 32, WAVE);
     }
+    __shared__ int row_mine[WIDE_PANEL];
+    if (lane == 0) row_mine[wave] = mine ? 1 : 0;
     if (!HALF || lane < 32) {
         const int cl = 2 * (HALF ? (lane & 31) : lane);
         ctile[cl][wave] = acc0;
@@ -596,7 +1263,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int ncols = min(TILE_COLS, n - col0);
     for (int idx = threadIdx.x; idx < TILE_COLS * WIDE_PANEL; idx += WIDE_WAVES * 64) {
         const int r = idx % WIDE_PANEL, j = idx / WIDE_PANEL;
-        if (r < nrows && j < ncols) {
+        if (r < nrows && j < ncols && row_mine[r]) {
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
             const double sres = alpha * ctile[j][r];
             *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
@@ -745,22 +1412,64 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
     return hipGetLastError();
 }
 
-hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx,
+hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
                                 double beta, double *C, int64_t ldc, int variant)
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
-        if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO) {
+        if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO || variant == SPMM_VARIANT_WINDOW2 ||
+            variant == SPMM_VARIANT_WINDOW3) {
+            const int2 *info = nullptr;
+            int info_rows = 1;
+            if (variant != SPMM_VARIANT_DIRECT_DPP) {
+                // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
+                const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
+                info_rows = gen2 ? W2_PANEL : W3_PANEL;
+                int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
+                const int np = (rows + info_rows - 1) / info_rows;
+                const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+                const int need = (int)(avg * 1.15 / 64.0) + 1;
+                const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+                hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
+                                   np, info_rows, rowptr, colidx, ch * 64, 1.0f, winfo);
+                dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
+                const char *ab = getenv("SBLAS_ABLATE"); /* diagnostics only: wrong results when set */
+                const int ablate = ab ? atoi(ab) : 0;
+#define SBLAS_W_LAUNCH(KERNEL, CHV)                                                                                  \
+    do {                                                                                                             \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set) {                                                                                             \
+            (void)hipFuncSetAttribute((const void *)KERNEL<CHV>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                      (int)W2_LDS_BYTES);                                                            \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
+                           ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
+    } while (0)
+                if (gen2) {
+                    if (ch == 1) SBLAS_W_LAUNCH(spmm_window2_kernel, 1);
+                    else if (ch == 2) SBLAS_W_LAUNCH(spmm_window2_kernel, 2);
+                    else if (ch == 4) SBLAS_W_LAUNCH(spmm_window2_kernel, 4);
+                    else SBLAS_W_LAUNCH(spmm_window2_kernel, 7);
+                } else {
+                    if (ch == 1) SBLAS_W_LAUNCH(spmm_window3_kernel, 1);
+                    else if (ch == 2) SBLAS_W_LAUNCH(spmm_window3_kernel, 2);
+                    else if (ch == 4) SBLAS_W_LAUNCH(spmm_window3_kernel, 4);
+                    else SBLAS_W_LAUNCH(spmm_window3_kernel, 7);
+                }
+#undef SBLAS_W_LAUNCH
+                info = winfo;
+            }
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
             if (ldbt == 64) {
                 dim3 grid((unsigned)wide_panels, 1u);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<true>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows);
             } else {
                 dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 128));
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<false>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc);
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows);
             }
         } else if (variant == SPMM_VARIANT_DIRECT) {
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
@@ -803,6 +1512,16 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, const int *ro
                            val, Bt, n, alpha, beta, C, ldc);
     }
     return hipGetLastError();
+}
+
+hipError_t prof_stats(unsigned long long out[16], bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 16 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z);
+    }
+    return e;
 }
 
 hipError_t panel_stats(unsigned long long out[4], bool reset)

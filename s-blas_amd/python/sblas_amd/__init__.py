@@ -18,7 +18,7 @@ EXPORTS = [
     "sblas_hip_version", "sblas_hip_error_string", "sblas_hip_device_count",
     "sblas_hip_spmm_csr_f64_i32_workspace", "sblas_hip_spmm_csr_f64_i32", "sblas_hip_spmm_ldbt",
     "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
-    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
+    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_spmm_cycle_stamps", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
     "sblas_mm_read_info", "sblas_mm_read_csr",
@@ -59,6 +59,8 @@ def lib():
     L.sblas_hip_dense_to_rowmajor_f64.argtypes = [C.c_int, vp, i64, i64, vp, i64, vp, i64]
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.restype = C.c_int
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64]
+    L.sblas_hip_debug_spmm_cycle_stamps.restype = C.c_int
+    L.sblas_hip_debug_spmm_cycle_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.sblas_hip_debug_spmm_panel_stats.restype = C.c_int
     L.sblas_hip_debug_spmm_panel_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.sblas_hip_spmv_csr_f64_i32.restype = C.c_int
@@ -192,6 +194,12 @@ def panel_stats(reset=True):
     out = (C.c_uint64 * 4)()
     check(lib().sblas_hip_debug_spmm_panel_stats(out, 1 if reset else 0), "sblas_hip_debug_spmm_panel_stats")
     return int(out[0]), int(out[1]), int(out[2])
+
+
+def cycle_stamps(reset=True):
+    out = (C.c_uint64 * 16)()
+    check(lib().sblas_hip_debug_spmm_cycle_stamps(out, 1 if reset else 0), "sblas_hip_debug_spmm_cycle_stamps")
+    return [int(x) for x in out]
 
 
 def spmv(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offset=0):

@@ -105,7 +105,7 @@ def test_ash85_spmm_known_answers(env, ash85, key):
     assert oracle.lib().orc_check_equal(ref, got, got.size) == 1          # the reference's own criterion (1e-3 abs)
 
 
-@pytest.mark.parametrize("variant", ["auto", "dpp", "direct"])
+@pytest.mark.parametrize("variant", ["auto", "dpp", "direct", "win2", "win3"])
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 130, 256])
 def test_spmm_every_column_count(env, variant_env, variant, n):
     sblas, oracle, torch, dev = env
@@ -159,7 +159,7 @@ def test_spmm_nonfinite_b_rows_not_referenced_stay_out(env, variant_env):
     B[:, 0] = np.nan
     B = np.ascontiguousarray(B).reshape(-1)
     C0 = rng.standard_normal(rows * n)
-    for variant in ("dpp", "win64", "auto"):
+    for variant in ("dpp", "win64", "win2", "win3", "auto"):
         variant_env(variant)
         got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
         ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
@@ -368,7 +368,7 @@ def test_full_size_properties(env):
 # ---------------------------------------------------------------------------------------------------------
 # the windowed (row panel x LDS B tile) kernel and its per-panel fallback
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["direct", "dpp", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
+@pytest.mark.parametrize("variant", ["direct", "dpp", "win2", "win3", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
 @pytest.mark.parametrize("shape", [(1000, 40, 100, 64), (777, 60, 300, 130), (200, 30, 20, 64), (90, 80, 45, 256)])
 def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     """Banded, ascending rows: dense enough over their span that the windowed path is taken.  Covers several
@@ -386,7 +386,7 @@ def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     assert close(got, ref), (variant, shape, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["win32", "win64", "win128", "win64w64"])
+@pytest.mark.parametrize("variant", ["win2", "win3", "win32", "win64", "win128", "win64w64"])
 @pytest.mark.parametrize("damage", ["all_descending", "one_row_shuffled", "first_col_not_min", "duplicates"])
 def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, damage):
     """The windowed path expects ascending columns but must never depend on it: panels whose rows break the
@@ -464,3 +464,35 @@ def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     oracle.spmm(300, K, n, *As.h, B, part, 1.0, 0.0)
     want[:, 100:400] += part.reshape(n, 300)
     assert close(Cd.cpu().numpy(), want.reshape(-1))
+
+
+def test_spmm_panel_census_paths_are_really_taken(env, variant_env):
+    """The parity tests above cannot tell a windowed run from a fallback run; the census can.  (win2: 48-row
+    panels; [0] windowed, [1] direct kernel, [2] windowed but recomputed by the in-kernel fallback.)"""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env("win2")
+    n = 64
+
+    def run(rp, ci, v, rows, cols):
+        A = Dev(torch, dev, rp, ci, v, cols)
+        rng = np.random.default_rng(1)
+        B, C0 = rng.standard_normal(cols * n), rng.standard_normal(rows * n)
+        sblas.panel_stats()
+        got = gpu_spmm(sblas, torch, dev, A, B, cols, n, 1.0, 1.0, C0, rows)
+        st = sblas.panel_stats()
+        assert close(got, oracle.spmm(rows, cols, n, *A.h, B, C0.copy(), 1.0, 1.0))
+        return st
+
+    rows = 480
+    rp, ci, v = synth.banded(rows, 60, 150)
+    assert run(rp, ci, v, rows, rows) == (10, 0, 0)                       # every panel through LDS
+    ci2, v2 = ci.copy(), v.copy()
+    ci2[rp[100]:rp[101]] = ci2[rp[100]:rp[101]][::-1]                     # one descending row in panel 2
+    v2[rp[100]:rp[101]] = v2[rp[100]:rp[101]][::-1]
+    assert run(rp, ci2, v2, rows, rows) == (9, 0, 1)                      # that panel recomputed, others not
+    rp3, ci3, v3 = synth.random_csr(rows, 5000, 6, seed=3, sorted_rows=True)
+    assert run(rp3, ci3, v3, rows, 5000) == (0, 10, 0)                    # too sparse over its span: direct kernel
+    rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows longer than the register budget (7*64)
+    w, d, f = run(rp4, ci4, v4, rows, rows)                               # (edge panels have shorter rows)
+    assert d >= 8 and f == 0 and w + d == 10
