@@ -171,7 +171,7 @@ def test_argument_validation_returns_codes_without_a_gpu(sblas):
     assert L.sblas_hip_axpby_f64(-1, None, -5, 1.0, one, 1.0, one) == 1
     assert L.sblas_hip_spmm_ldbt(64) == 64 and L.sblas_hip_spmm_ldbt(65) == 128 and L.sblas_hip_spmm_ldbt(8) == 8
     assert L.sblas_hip_spmm_ldbt(33) == 64 and L.sblas_hip_spmm_ldbt(129) == 256
-    assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8   # + the all-zero row
+    assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8 + 1 * 8 + 16   # Bt + zero row, panel verdicts
     assert b"workspace" in L.sblas_hip_error_string(3)
 
 
