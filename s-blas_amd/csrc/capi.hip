@@ -185,7 +185,7 @@ int sblas_hip_spmv_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (!y || (cols > 0 && !x)) return SBLAS_E_INVALID;
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
-    return sblas::launch_spmv((hipStream_t)stream, (int)rows, nnz, rowptr, colidx, val, x, alpha, beta, y) ==
+    return sblas::launch_spmv((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, val, x, alpha, beta, y) ==
                    hipSuccess
                ? SBLAS_OK
                : SBLAS_E_HIP;

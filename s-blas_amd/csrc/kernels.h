@@ -23,7 +23,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                 double beta, double *C, int64_t ldc, int variant);
 hipError_t panel_stats(unsigned long long out[4], bool reset);
 hipError_t prof_stats(unsigned long long out[16], bool reset);
-hipError_t launch_spmv(hipStream_t s, int rows, int64_t nnz, const int *rowptr, const int *colidx,
+hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                        const double *val, const double *x, double alpha, double beta, double *y);
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y);
 hipError_t launch_sum_replicas(hipStream_t s, const ReplicaPtrs &bufs, int g, int64_t n);

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "kernels.h"
 
 namespace sblas {
@@ -1338,6 +1339,7 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
     if (row < rows) {
         const int p1 = rowptr[row + 1];
         int p = rowptr[row] + l;
+        // two slices per trip (four gave fewer resident waves and ran 20 % slower)
         for (; p + LPR < p1; p += 2 * LPR) {
             const int c0 = colidx[p], c1 = colidx[p + LPR];
             const double a0 = val[p], a1 = val[p + LPR];
@@ -1352,6 +1354,148 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
     if (row < rows && l == 0) {
         const double r = alpha * s;
         y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for long rows, burst form.  The generic kernel is latency-bound (SQ_WAIT_ANY 86 %, ~650 cycles per
+// L1->L2 request): a 400-nonzero row walks four dependent trips of {col/val load -> x gather -> FMA}.  Here a wave
+// issues the (col, val) loads of up to 512 nonzeros of its row back to back, then all x gathers, then the FMAs:
+// one memory round trip per stage per 512 nonzeros, 16 independent loads in flight per lane.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmv_csr_burst_kernel(int rows, const int *__restrict__ rowptr,
+                                                            const int *__restrict__ colidx,
+                                                            const double *__restrict__ val,
+                                                            const double *__restrict__ x, double alpha, double beta,
+                                                            double *__restrict__ y)
+{
+    constexpr int S = 8; // slices of 64 nonzeros per burst
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int p0 = wave_uniform(rowptr[row]), p1 = wave_uniform(rowptr[row + 1]);
+    double s0 = 0.0, s1 = 0.0;
+    for (int base = p0; base < p1; base += S * WAVE) {
+        int c[S];
+        double a[S], xv[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int p = base + u * WAVE + lane;
+            c[u] = 0;
+            a[u] = 0.0;
+            if (p < p1) {
+                c[u] = colidx[p];
+                a[u] = val[p];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int p = base + u * WAVE + lane;
+            xv[u] = (p < p1) ? x[c[u]] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < S; u += 2) {
+            s0 = fma(a[u], xv[u], s0);
+            s1 = fma(a[u + 1], xv[u + 1], s1);
+        }
+    }
+    double sum = s0 + s1;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+    if (lane == 0) {
+        const double r = alpha * sum;
+        y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV with the x window of a row block staged in LDS.
+// The plain kernel is bound by the address unit, not by HBM: per 64 nonzeros it issues two coalesced loads
+// (col_idx, val) and one 64-address gather of x, and the gather keeps the unit busy about twice as long as both
+// streams together.  Here a workgroup of 8 waves owns 16 consecutive rows (two per wave, so the CU still holds 32
+// waves), guesses their column window from the first/last column of each row, copies x[lo, hi] into LDS with
+// coalesced loads and gathers from LDS.  Any column outside the staged window -- unsorted rows, outliers, windows
+// larger than the LDS budget -- is read from global memory by that lane: the result never depends on the guess.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPMV_BLOCK_ROWS = 16;
+constexpr int SPMV_WINDOW_CAP = 4608; // doubles (36 KiB): four workgroups = 32 waves per CU
+
+__global__ __launch_bounds__(512) void spmv_csr_window_kernel(int rows, int cols, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ colidx,
+                                                             const double *__restrict__ val,
+                                                             const double *__restrict__ x, double alpha, double beta,
+                                                             double *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    __shared__ int sm_lo, sm_hi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = blockIdx.x * SPMV_BLOCK_ROWS;
+    if (tid == 0) {
+        sm_lo = 0x7fffffff;
+        sm_hi = -1;
+    }
+    // this wave's two rows (their pointers are fetched before the window is known)
+    const int rowA = row0 + wave * 2, rowB = rowA + 1;
+    int pa0 = 0, pa1 = 0, pb1 = 0;
+    if (rowA < rows) {
+        pa0 = wave_uniform(rowptr[rowA]);
+        pa1 = wave_uniform(rowptr[rowA + 1]);
+        pb1 = (rowB < rows) ? wave_uniform(rowptr[rowB + 1]) : pa1;
+    }
+    __syncthreads();
+    if (lane == 0 && pb1 > pa0) {
+        int first = (pa1 > pa0) ? colidx[pa0] : colidx[pa1];
+        int last = (pb1 > pa1) ? colidx[pb1 - 1] : colidx[pa1 - 1];
+        if (pa1 > pa0 && pb1 > pa1) { // both rows non-empty: the window must cover both ends of both
+            first = min(first, colidx[pa1]);
+            last = max(last, colidx[pa1 - 1]);
+        }
+        atomicMin(&sm_lo, first);
+        atomicMax(&sm_hi, last);
+    }
+    __syncthreads();
+    int lo = sm_lo, hi = sm_hi;
+    if (lo > hi) {
+        lo = 0;
+        hi = -1;
+    }
+    if (lo < 0) lo = 0;
+    if (hi >= cols) hi = cols - 1;
+    int wlen = hi - lo + 1;
+    if (wlen > SPMV_WINDOW_CAP) wlen = SPMV_WINDOW_CAP; // keep the first part of an oversized window
+    for (int i = tid; i < wlen; i += 512) xs[i] = x[lo + i];
+    __syncthreads();
+
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const int row = which ? rowB : rowA;
+        const int p0 = which ? pa1 : pa0, p1 = which ? pb1 : pa1;
+        if (row >= rows) break;
+        double s0 = 0.0, s1 = 0.0;
+        int p = p0 + lane;
+        for (; p + WAVE < p1; p += 2 * WAVE) {
+            const int c0 = colidx[p], c1 = colidx[p + WAVE];
+            const double a0 = val[p], a1 = val[p + WAVE];
+            const unsigned r0 = (unsigned)(c0 - lo), r1 = (unsigned)(c1 - lo);
+            const double x0 = (r0 < (unsigned)wlen) ? xs[r0] : x[c0];
+            const double x1 = (r1 < (unsigned)wlen) ? xs[r1] : x[c1];
+            s0 = fma(a0, x0, s0);
+            s1 = fma(a1, x1, s1);
+        }
+        if (p < p1) {
+            const int c0 = colidx[p];
+            const unsigned r0 = (unsigned)(c0 - lo);
+            const double x0 = (r0 < (unsigned)wlen) ? xs[r0] : x[c0];
+            s0 = fma(val[p], x0, s0);
+        }
+        double sum = s0 + s1;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+        if (lane == 0) {
+            const double r = alpha * sum;
+            y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+        }
     }
 }
 
@@ -1544,10 +1688,25 @@ static hipError_t spmv_go(hipStream_t s, int rows, const int *rowptr, const int 
     return hipGetLastError();
 }
 
-hipError_t launch_spmv(hipStream_t s, int rows, int64_t nnz, const int *rowptr, const int *colidx,
+hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                        const double *val, const double *x, double alpha, double beta, double *y)
 {
     const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    // Default: the generic lanes-per-row kernel (fastest measured in round 1: 4.1 TB/s on the bench matrix).
+    // SBLAS_SPMV_VARIANT=burst|window selects the two experimental long-row kernels (both correct, both slower:
+    // 116 us and 83 us vs 82 us) for A/B runs and tests.
+    const char *sv = getenv("SBLAS_SPMV_VARIANT");
+    if (avg > 96.0 && sv && !strcmp(sv, "burst")) {
+        hipLaunchKernelGGL(spmv_csr_burst_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, rowptr,
+                           colidx, val, x, alpha, beta, y);
+        return hipGetLastError();
+    }
+    if (avg > 48.0 && sv && !strcmp(sv, "window")) {
+        hipLaunchKernelGGL(spmv_csr_window_kernel, dim3((unsigned)((rows + SPMV_BLOCK_ROWS - 1) / SPMV_BLOCK_ROWS)),
+                           dim3(512), SPMV_WINDOW_CAP * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha,
+                           beta, y);
+        return hipGetLastError();
+    }
     if (avg <= 6.0) return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
     if (avg <= 12.0) return spmv_go<8>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
     if (avg <= 24.0) return spmv_go<16>(s, rows, rowptr, colidx, val, x, alpha, beta, y);

@@ -496,3 +496,46 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env):
     rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows longer than the register budget (7*64)
     w, d, f = run(rp4, ci4, v4, rows, rows)                               # (edge panels have shorter rows)
     assert d >= 8 and f == 0 and w + d == 10
+
+
+@pytest.fixture
+def spmv_variant_env():
+    old = os.environ.get("SBLAS_SPMV_VARIANT")
+    yield lambda v: os.environ.__setitem__("SBLAS_SPMV_VARIANT", v)
+    if old is None:
+        os.environ.pop("SBLAS_SPMV_VARIANT", None)
+    else:
+        os.environ["SBLAS_SPMV_VARIANT"] = old
+
+
+@pytest.mark.parametrize("variant", ["plain", "burst", "window"])
+@pytest.mark.parametrize("kind", ["banded", "unsorted", "wide_span", "outliers"])
+def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
+    """Long rows (the 64-lanes-per-row instantiation, unrolled four slices deep): banded, shuffled, very wide spans
+    and far-away outlier columns; the default kernel and the two experimental long-row kernels (one stages the x
+    window in LDS and must fall back lane by lane for columns outside it)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    spmv_variant_env(variant)
+    rng = np.random.default_rng(5)
+    if kind == "wide_span":
+        M = K = 60000
+        rp, ci, v = synth.banded(M, 100, 20000)          # span 40 000 > LDS window
+    else:
+        M = K = 5000
+        rp, ci, v = synth.banded(M, 120, 700)
+    ci, v = ci.copy(), v.copy()
+    if kind == "unsorted":
+        for r in range(0, M, 3):
+            perm = rng.permutation(rp[r + 1] - rp[r])
+            ci[rp[r]:rp[r + 1]] = ci[rp[r]:rp[r + 1]][perm]
+            v[rp[r]:rp[r + 1]] = v[rp[r]:rp[r + 1]][perm]
+    if kind == "outliers":
+        ci[rp[:-1][::5] + 7] = rng.integers(0, K, len(rp[:-1][::5]))       # one far-away column in every 5th row
+    A = Dev(torch, dev, rp, ci, v, K)
+    xh, yh = rng.standard_normal(K), rng.standard_normal(M)
+    for alpha, beta in ((1.0, 1.0), (-0.5, 0.0)):
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
+        ref = oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)
+        assert close(y.cpu().numpy(), ref), (kind, alpha, beta)
