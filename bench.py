@@ -135,7 +135,7 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.dist_backend == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     t_k = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="row-count scale of the synthetic stand-in (rehearsal only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-method2", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo + --fold-ranks rehearses the N>1 code path on one GPU")
+    ap.add_argument("--fold-ranks", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--op", choices=["spmm", "spmv"], default="spmm",
                     help="spmm (the headline metric) or spmv (same matrix, x = y0 = 1; secondary measurement)")
     args = ap.parse_args()
@@ -185,13 +188,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.fold_ranks:
+        local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK=%d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if dist is not None:
@@ -234,7 +244,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     t_stage1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
@@ -297,7 +307,12 @@ def main():
             S.dense_to_rowmajor(cols, n, B2, cols, Bt)
             S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 1.0, Ccopy, rows, c_offset=part["start_row"])
             if k is not None: e[k][1].record()
-            dist.all_reduce(Ccopy)                            # spmm.h:260-262, RCCL over xGMI
+            if args.dist_backend == "nccl":
+                dist.all_reduce(Ccopy)                        # spmm.h:260-262, RCCL over xGMI
+            else:                                             # rehearsal: gloo on a host copy
+                h = Ccopy.cpu()
+                dist.all_reduce(h)
+                Ccopy.copy_(h)
             if k is not None: e[k][2].record()
             S.axpby(rows * n, 1.0, Ccopy, 1.0, C2)            # spmm.h:283 -> kernel.h:27-38
             if k is not None: e[k][3].record()
@@ -312,10 +327,23 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el2 = time.perf_counter() - t0
-        t = torch.tensor([el2], dtype=torch.float64, device=dev)
+        t = torch.tensor([el2], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el2 = float(t.item())
+        # method-2 result check on rank 0: C2 = 1 + (warmup+steps) * A*B2 on 64 sampled rows
+        m2_ok = None
+        if rank == 0:
+            import oracle_py as O2
+            r0 = rows // 2
+            ref2 = np.zeros(rows * n)
+            O2.spmm_rows(r0, r0 + 64, rows, cols, n, rp, ci, v, B2.cpu().numpy(), ref2, 1.0, 0.0)
+            got2 = C2.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
+            want2 = 1.0 + total_steps * ref2.reshape(n, rows)[:, r0:r0 + 64]
+            m2_ok = bool(np.allclose(got2, want2, rtol=1e-9, atol=1e-9))
+            if not m2_ok:
+                raise SystemExit("method-2 bench result does not match the oracle: max diff %g" % np.abs(got2 - want2).max())
         out["method2"] = {
+            "oracle_check": m2_ok,
             "scaling": "strong", "n_total_cols": n, "gflops": round(flops_step * args.steps / el2 / 1e9, 2),
             "ms_per_step": round(el2 / args.steps * 1e3, 5),
             "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e])), 5),
