@@ -94,13 +94,38 @@ int64_t sblas_hip_spmm_ldbt(int64_t n)
     return (n + 127) / 128 * 128; // wide tiles are 128 columns (two per lane)
 }
 
+// The kernels address Bt with 32-bit byte offsets, so one stage-2 launch can cover at most 4 GiB of Bt.  The
+// top-level call therefore walks the dense columns in chunks of `w` columns with (cols+1)*ldbt(w)*8 <= 4 GiB
+// (Queen_4147 with N = 256: two chunks of 128).  SBLAS_SPMM_MAX_BT_BYTES lowers the limit (tests).
+static uint64_t bt_byte_limit()
+{
+    const char *e = getenv("SBLAS_SPMM_MAX_BT_BYTES");
+    if (e && *e) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 4096 && v < 0xffffffffull) return v;
+    }
+    return 0xffffffffull;
+}
+
+static int64_t spmm_chunk_cols(int64_t cols, int64_t n)
+{
+    const uint64_t lim = bt_byte_limit();
+    const uint64_t row_bytes = 8ull * ((uint64_t)cols + 1);
+    if (row_bytes * (uint64_t)sblas_hip_spmm_ldbt(n) <= lim) return n;
+    for (int64_t w = (n / 128) * 128; w >= 128; w -= 128)
+        if (row_bytes * (uint64_t)w <= lim) return w;
+    if (row_bytes * 64ull <= lim) return 64;
+    return 32; // the narrow kernels use 64-bit addressing: no limit
+}
+
 size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
 {
     (void)nnz;
     if (cols <= 0 || n <= 0) return 0;
-    // Bt plus one extra all-zero row (the target of masked DPP slots), then one int2 per 48-row panel (the
-    // panel classifier's verdicts)
-    const size_t bt = ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(n) * sizeof(double);
+    // Bt for one column chunk plus one extra all-zero row (the target of masked DPP slots), then one int2 per
+    // row panel (the panel classifier's verdicts)
+    const int64_t w = spmm_chunk_cols(cols, n);
+    const size_t bt = ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(w) * sizeof(double);
     const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_WINDOW2_PANEL_ROWS - 1) / sblas::SPMM_WINDOW2_PANEL_ROWS;
     return bt + panels * 8 + 16;
 }
@@ -129,7 +154,7 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     if (ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
     if (cols > 0 && !Bt) return SBLAS_E_INVALID;
     // the kernels address Bt with 32-bit element offsets (row * ldbt + column)
-    if (((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_E_INVALID; // 32-bit byte offsets
+    if (ldbt >= 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_E_INVALID; // 32-bit byte offsets
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID; // 16-byte tile loads
@@ -150,12 +175,18 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (cols > 0 && (!B || ldb < cols)) return SBLAS_E_INVALID;
     const size_t need = sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
-    const int64_t ldbt = sblas_hip_spmm_ldbt(n);
     double *Bt = static_cast<double *>(workspace);
-    int rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, n, B, ldb, Bt, ldbt);
-    if (rc != SBLAS_OK) return rc;
-    return sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n,
-                                                alpha, beta, C, ldc);
+    const int64_t w = spmm_chunk_cols(cols, n);
+    for (int64_t j0 = 0; j0 < n; j0 += w) { // one pass unless Bt would exceed the 32-bit offset window
+        const int64_t nj = (n - j0 < w) ? n - j0 : w;
+        const int64_t ldbt = sblas_hip_spmm_ldbt(nj);
+        int rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt);
+        if (rc != SBLAS_OK) return rc;
+        rc = sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, nj, alpha,
+                                                  beta, C + j0 * ldc, ldc);
+        if (rc != SBLAS_OK) return rc;
+    }
+    return SBLAS_OK;
 }
 
 int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset)

@@ -1,6 +1,6 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, 's-blas_amd/python')
-os.environ['SBLAS_SPMM_VARIANT'] = 'win2'
+os.environ['SBLAS_SPMM_VARIANT'] = os.environ.get('SBLAS_SPMM_VARIANT', 'win3')
 os.environ['SBLAS_ABLATE'] = '4'
 import sblas_amd as S
 from sblas_amd import synth
@@ -19,5 +19,5 @@ for it in range(3):
 nc, nl = g[7], g[8]
 print('consumer waves', nc, 'loader waves', nl, '(per-wave averages in shader cycles, per panel)')
 print('consumer: prologue %.0f  visits %.0f  barrier-wait %.0f' % (g[0]/nc, g[1]/nc, g[2]/nc))
-print('loader  : put %.0f  fetch-issue %.0f  barrier-wait %.0f' % (g[4]/nl, g[5]/nl, g[6]/nl))
+print('loader  : put|dma-issue %.0f  fetch-issue|dma-wait %.0f  barrier-wait %.0f' % (g[4]/nl, g[5]/nl, g[6]/nl))
 print('whole-wave avg %.0f' % (g[9]/(nc+nl)))

@@ -539,3 +539,29 @@ def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
         sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
         ref = oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)
         assert close(y.cpu().numpy(), ref), (kind, alpha, beta)
+
+
+@pytest.mark.parametrize("n", [64, 200, 256, 300])
+def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
+    """BASELINE config 5 shape problem (Queen_4147, N = 256: the row-major copy of B is 8.5 GB) in miniature: with the
+    Bt byte limit lowered, the top-level call must walk the dense columns in chunks (128 / 64 / 32 wide) and still
+    match the oracle; the workspace query must shrink accordingly."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    M = K = 700
+    rp, ci, v = synth.banded(M, 30, 60)
+    A = Dev(torch, dev, rp, ci, v, K)
+    rng = np.random.default_rng(n)
+    B, C0 = rng.standard_normal(K * n), rng.standard_normal(M * n)
+    ref = oracle.spmm(M, K, n, *A.h, B, C0.copy(), 1.5, -1.0)
+    full = sblas.spmm_workspace_bytes(M, K, len(ci), n)
+    for limit, width in ((8 * 701 * 128, 128), (8 * 701 * 64, 64), (8 * 701 * 40, 32)):
+        os.environ["SBLAS_SPMM_MAX_BT_BYTES"] = str(limit)
+        try:
+            ws = sblas.spmm_workspace_bytes(M, K, len(ci), n)
+            if n > width:
+                assert ws < full
+            got = gpu_spmm(sblas, torch, dev, A, B, K, n, 1.5, -1.0, C0, M)
+        finally:
+            os.environ.pop("SBLAS_SPMM_MAX_BT_BYTES", None)
+        assert close(got, ref), (n, width, np.abs(got - ref).max())
