@@ -913,7 +913,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
     const unsigned ld32 = (unsigned)ldbt;
     const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
     const bool loader = wave >= W2_NCONS;
-    (void)ablate;
+    const bool no_load = (ablate & 8) != 0, no_math = (ablate & 2) != 0; // diagnostics (wrong results)
 
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
@@ -953,7 +953,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
         if (t_lo < t_hi) fetch(t_lo + 1);
         __syncthreads(); // P
         for (int t = t_lo; t <= t_hi; ++t) {
-            if (t < t_hi) {
+            if (t < t_hi && !no_load) {
                 put(((t - t_lo) & 1) ^ 1);
                 if (t + 1 < t_hi) fetch(t + 2);
             }
@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
                         const double gv = on ? wv[r] : 0.0;
                         const int npairs = (take + 7) >> 3; // pairs of 4-nonzero steps
                         double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
+                        if (!no_math) {
                         SBLAS_QPAIR(0, 1)
                         SBLAS_QPAIR(2, 3)
                         SBLAS_QPAIR(4, 5)
@@ -1045,6 +1046,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
                         SBLAS_QPAIR(10, 11)
                         SBLAS_QPAIR(12, 13)
                         SBLAS_QPAIR(14, 15)
+                        }
                         acc[r][0] = q0;
                         acc[r][1] = q1;
                         acc[r][2] = q2;

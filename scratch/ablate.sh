@@ -1,5 +1,5 @@
 #!/bin/bash
-for a in 0 1 2 3; do
-  SBLAS_ABLATE=$a SBLAS_SPMM_VARIANT=win2 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('ablate=$a kernel=%.4f ms check=%s' % (r['kernel_ms'], d['oracle_check']))"
+for a in 0 2 8 10; do
+  SBLAS_ABLATE=$a SBLAS_SPMM_VARIANT=win3 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 2>/dev/null | python -c "
+import json,sys; d=json.load(sys.stdin); r=d['roofline']; print('ablate=$a (2=no consumer math, 8=no tile loads) kernel=%.4f ms' % (r['kernel_ms']))"
 done
