@@ -914,6 +914,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
     const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
     const bool loader = wave >= W2_NCONS;
     const bool no_load = (ablate & 8) != 0, no_math = (ablate & 2) != 0; // diagnostics (wrong results)
+    const bool no_bar = (ablate & 16) != 0, no_a = (ablate & 32) != 0, no_shift = (ablate & 64) != 0;
 
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
                 put(((t - t_lo) & 1) ^ 1);
                 if (t + 1 < t_hi) fetch(t + 2);
             }
-            __syncthreads(); // E_t
+            if (!no_bar) __syncthreads(); // E_t
         }
         __syncthreads(); // V
     } else {
@@ -981,6 +982,16 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
+            if (no_a) { // synthetic ascending columns inside the panel's span, no memory traffic
+                wc[r] = span.x + eidx * 9;
+                wv[r] = 1.0;
+#pragma unroll
+                for (int q = 1; q < CH; ++q) {
+                    sc[r][q - 1] = min(span.x + (64 * q + eidx) * 9, span.y);
+                    sv[r][q - 1] = 1.0;
+                }
+                continue;
+            }
             load_chunk_quad(colidx, val, p0[r], p0[r] + len[r], eidx, wc[r], wv[r]);
 #pragma unroll
             for (int q = 1; q < CH; ++q)
@@ -1054,7 +1065,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
                     }
                     // slide the window: entry e of the new window is entry e+take of the old one
                     const int rest = wcnt[r] - take;
-                    if (rest > 0) {
+                    if (rest > 0 && !no_shift) {
                         const int se = eidx + take;
                         const int src = lane_of_entry(se & 63) << 2;
                         // lanes >= rest receive stale entries; every use of the window is masked by wcnt, so they
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
                     if (rest > 0) break; // what is left belongs to later tiles
                 }
             }
-            __syncthreads(); // E_t
+            if (!no_bar) __syncthreads(); // E_t
         }
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -1584,12 +1595,9 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const int ablate = ab ? atoi(ab) : 0;
 #define SBLAS_W_LAUNCH(KERNEL, CHV)                                                                                  \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)KERNEL<CHV>, hipFuncAttributeMaxDynamicSharedMemorySize,         \
-                                      (int)W2_LDS_BYTES);                                                            \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        /* per device and cheap: set on every launch (one process may drive several GPUs) */                        \
+        (void)hipFuncSetAttribute((const void *)KERNEL<CHV>, hipFuncAttributeMaxDynamicSharedMemorySize,             \
+                                  (int)W2_LDS_BYTES);                                                                \
         hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
@@ -1629,12 +1637,9 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         constexpr int R = 16 * RPW;                                                                                  \
         const int np = (rows + R - 1) / R;                                                                           \
         dim3 grid((unsigned)np, (unsigned)(ldbt / 64));                                                              \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            (void)hipFuncSetAttribute((const void *)spmm_window_kernel<RPW, W, MW>,                                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds_bytes(W));            \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
+        /* per device and cheap: set on every launch (one process may drive several GPUs) */                        \
+        (void)hipFuncSetAttribute((const void *)spmm_window_kernel<RPW, W, MW>,                                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_lds_bytes(W));                \
         hipLaunchKernelGGL((spmm_window_kernel<RPW, W, MW>), grid, dim3(WIN_THREADS), win_lds_bytes(W), s, rows,     \
                            cols, np, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, dens);                   \
     } while (0)
