@@ -26,6 +26,8 @@ def _load():
     lib.orc_mm_data.restype = C.c_int
     lib.orc_spmm_csr.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_double]
     lib.orc_spmm_csr.restype = None
+    lib.orc_spmm_csr_omp.argtypes = lib.orc_spmm_csr.argtypes
+    lib.orc_spmm_csr_omp.restype = None
     lib.orc_spmm_csr_rows.argtypes = [C.c_int, C.c_int] + lib.orc_spmm_csr.argtypes
     lib.orc_spmm_csr_rows.restype = None
     lib.orc_spmv_csr.argtypes = [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_double]
@@ -102,6 +104,11 @@ def read_mtx_ref(path):
 def spmm(M, K, N, rowptr, colidx, val, B, C_, alpha, beta):
     """In place on C_ (column-major flat array of M*N)."""
     lib().orc_spmm_csr(M, K, N, rowptr, colidx, val, B, C_, alpha, beta)
+    return C_
+
+
+def spmm_omp(M, K, N, rowptr, colidx, val, B, C_, alpha, beta):
+    lib().orc_spmm_csr_omp(M, K, N, rowptr, colidx, val, B, C_, alpha, beta)
     return C_
 
 

@@ -240,6 +240,23 @@ void orc_spmm_csr_rows(int r0, int r1, int M, int K, int N, const int *rowptr,
     }
 }
 
+/* The same loop with the rows spread over OpenMP threads (rows are independent): bench.py's "all host cores"
+ * figure.  The reference itself is single-threaded; arithmetic per element is unchanged. */
+void orc_spmm_csr_omp(int M, int K, int N, const int *rowptr, const int *colidx, const double *val,
+                      const double *B, double *C, double alpha, double beta)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < M; ++i) {
+        for (int n = 0; n < N; ++n) {
+            double sum = 0;
+            for (int j = rowptr[i]; j < rowptr[i + 1]; ++j)
+                sum += val[j] * B[(size_t)n * (size_t)K + (size_t)colidx[j]];
+            size_t at = (size_t)n * (size_t)M + (size_t)i;
+            C[at] = beta * C[at] + alpha * sum;
+        }
+    }
+}
+
 /* sblas_spmv_csr_cpu, spmv.h:22-31. */
 void orc_spmv_csr(int M, const int *rowptr, const int *colidx, const double *val,
                   const double *x, double *y, double alpha, double beta)

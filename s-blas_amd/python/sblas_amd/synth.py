@@ -55,6 +55,36 @@ def nd24k_like(scale=1.0):
     return rows, banded(rows, 399, 2000)
 
 
+def queen_like(rows, seed=SEED, half_band=50000):
+    """Stand-in for SuiteSparse Queen_4147 (M = 4 147 110, ~76 nnz/row, 3-D structural FEM): every row holds 20..30
+    clusters of 3 consecutive columns (3 dofs per mesh node) at stencil-like offsets inside +-half_band, the diagonal
+    cluster always present; ascending, duplicate-free.  `rows` scales the matrix (band is clipped to it)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    hb = min(half_band, max(3, rows // 2 - 3))
+    noff = 40
+    offsets = np.unique(np.concatenate([[0], (rng.integers(-hb, hb + 1, noff) // 3) * 3]))
+    nclus = rng.integers(20, 31, rows)
+    rowptr = np.zeros(rows + 1, np.int64)
+    cols_list = []
+    for r0 in range(0, rows, 65536):
+        r1 = min(rows, r0 + 65536)
+        chunk = []
+        for r in range(r0, r1):
+            pick = np.sort(rng.choice(len(offsets), min(nclus[r], len(offsets)), replace=False))
+            base = (r // 3) * 3 + offsets[pick]
+            base = base[(base >= 0) & (base + 2 < rows)]
+            if base.size == 0:
+                base = np.array([min(max((r // 3) * 3, 0), rows - 3)])
+            c = (base[:, None] + np.arange(3)[None, :]).reshape(-1)
+            chunk.append(np.unique(c))
+            rowptr[r + 1] = chunk[-1].size
+        cols_list.extend(chunk)
+    np.cumsum(rowptr, out=rowptr)
+    colidx = np.concatenate(cols_list).astype(np.int32)
+    val = rng.random(colidx.size) * 2.0 - 1.0
+    return rowptr.astype(np.int32), colidx, val
+
+
 def random_csr(rows, cols, avg_nnz, seed=SEED, sorted_rows=False, empty_every=0, long_row=None):
     """Unstructured test matrix: duplicate columns allowed, rows unsorted unless asked, optional
     empty rows (every `empty_every`-th) and one long row (index, length)."""

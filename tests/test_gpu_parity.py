@@ -565,3 +565,25 @@ def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
         finally:
             os.environ.pop("SBLAS_SPMM_MAX_BT_BYTES", None)
         assert close(got, ref), (n, width, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("variant", ["auto", "dpp"])
+def test_spmm_queen_like_n256(env, variant_env, variant):
+    """BASELINE config 5 shape (Queen_4147-like stencil rows, N = 256) at reduced size: wide spans send every panel to
+    the direct kernel, 128-column tiles, four column tiles."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    rows, n = 6000, 256
+    rp, ci, v = synth.queen_like(rows, half_band=2500)
+    assert 55 < len(ci) / rows < 95 and all((np.diff(ci[rp[r]:rp[r + 1]]) > 0).all() for r in (0, 1, 2999, rows - 1))
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(8)
+    B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    sblas.panel_stats()
+    got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
+    st = sblas.panel_stats()
+    ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
+    assert close(got, ref)
+    if variant == "auto":
+        assert st[0] == 0 and st[1] > 0 and st[2] == 0        # nothing windowed, nothing fell back
