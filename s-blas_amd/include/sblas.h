@@ -1,8 +1,5 @@
-// sblas.h -- umbrella header of the S-BLAS API on MI355X (reference sblas.h:18-19).
-#ifndef SBLAS_AMD_SBLAS_H
-#define SBLAS_AMD_SBLAS_H
-
-#include "spmm.h"
+// sblas.h -- umbrella header of the S-BLAS API on MI355X: pulls in the SpMV and SpMM operators (and through them the
+// containers of matrix.h).  Mirrors the role of the reference's sblas.h:18-19.
+#pragma once
 #include "spmv.h"
-
-#endif
+#include "spmm.h"
