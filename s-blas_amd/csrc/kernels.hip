@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 #include "kernels.h"
 
@@ -1141,6 +1142,276 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form, fourth generation: streaming quad consumer.
+//
+// Ablation of the third generation: > half of its time is fixed cost per panel (A burst, per-visit bookkeeping,
+// barriers, epilogue) because a wave can keep only three whole rows in registers -> 36-row panels.  Here a
+// consumer wave keeps NO row data resident: at every (row, tile) visit it uses a 64-entry window loaded from
+// col_idx/val at the row's cursor (quad order, so the first `take` entries are DPP steps 0..take/4 -- no shift, no
+// chunk switch, no limit on the row length), issued NBUF-1 visits ahead into a ring of NBUF register buffers with
+// hand-counted vmcnt waits (hipcc's own bookkeeping turns conservative in this loop and would wait for the prefetch
+// just issued).  The re-reads hit L2 (the window advances ~12 entries per tile).  State per row = cursor + 4
+// accumulators.  Measured: what matters is the latency of a visit, not the panel size -- 4 rows per wave with a
+// 4-deep ring runs 509 us, 6 rows / 3-deep 842 us, 8 rows / 4-deep 1244 us, 2 rows / 2-deep 653 us.
+// Every consumed entry is checked to lie inside the current tile and the consumed set to be a prefix of the window;
+// anything else marks the panel for the direct-loop fallback.
+// ---------------------------------------------------------------------------------------------
+constexpr int W4_RPW = 4;
+constexpr int W4_PANEL = W2_NCONS * W4_RPW; // rows per panel
+constexpr int W4_NBUF = 4;                  // window buffers: the window of a visit is issued NBUF-1 visits ahead
+
+// Window loads of the streaming consumer, hidden from hipcc's vmcnt bookkeeping (which turns conservative in the
+// visit loop and would wait for the prefetch just issued): the loads are issued in one asm statement and retired by
+// a counted wait that names their destinations, so no compiler-generated use can be scheduled before the data has
+// landed (cdna_hip_programming.md section 5.7, form (ii)).  Indices are clamped instead of predicated; entries past
+// the row end are ignored by the caller (every use is masked by the window count).
+__device__ __forceinline__ void window_issue(const int *__restrict__ colidx, const double *__restrict__ val, int idx,
+                                             int &c, double &v)
+{
+    const int *pc = colidx + idx;
+    const double *pv = val + idx;
+    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                 : "=&v"(c), "=&v"(v)
+                 : "v"(pc), "v"(pv)
+                 : "memory");
+}
+// wait until at most `NEWER` younger vector-memory operations are outstanding
+template <int NEWER> __device__ __forceinline__ void window_wait(int &c, double &v)
+{
+    static_assert(NEWER == 0 || NEWER == 2 || NEWER == 4 || NEWER == 6, "two loads per window");
+    if (NEWER == 6) asm volatile("s_waitcnt vmcnt(6)" : "+v"(c), "+v"(v)::"memory");
+    else if (NEWER == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(c), "+v"(v)::"memory");
+    else if (NEWER == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(c), "+v"(v)::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(c), "+v"(v)::"memory");
+}
+
+__global__ __launch_bounds__(1024) void spmm_window4_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int ablate, int nnz)
+{
+    constexpr int RPW = W4_RPW, R = W4_PANEL;
+    constexpr int WIN = 32; // window entries fetched per visit (the L2 must keep every row's window between two visits)
+    static_assert(64 * (R + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zero_row = smem + 2 * W2_TILE;
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    const int2 span = info[panel];
+    if (span.x > span.y) return; // the direct kernel owns this panel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * R;
+    const int col0 = blockIdx.y * 64;
+    const unsigned ld32 = (unsigned)ldbt;
+    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const bool loader = wave >= W2_NCONS;
+    (void)ablate;
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    double acc[RPW][4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.0;
+
+    if (loader) {
+        const int ltid = tid - W2_NCONS * 64;
+        double2 st[16];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                const int brow = t * W2_ROWS + (q >> 5);
+                double2 x = make_double2(0.0, 0.0);
+                if (brow < cols)
+                    x = *reinterpret_cast<const double2 *>(Bt + (size_t)((unsigned)brow * ld32) + col0 + ((q & 31) << 1));
+                st[i] = x;
+            }
+        };
+        auto put = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = ltid + 256 * i;
+                *reinterpret_cast<double2 *>(smem + buf * W2_TILE + (q << 1)) = st[i];
+            }
+        };
+        fetch(t_lo);
+        put(0);
+        if (t_lo < t_hi) fetch(t_lo + 1);
+        __syncthreads(); // P
+        for (int t = t_lo; t <= t_hi; ++t) {
+            if (t < t_hi) {
+                put(((t - t_lo) & 1) ^ 1);
+                if (t + 1 < t_hi) fetch(t + 2);
+            }
+            __syncthreads(); // E_t
+        }
+        __syncthreads(); // V
+    } else {
+        const int eidx = ((lane & 15) << 2) + (lane >> 4); // window entry held by this lane (quad order)
+        int cur[RPW], end[RPW];
+        int bad = 0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = row0 + wave * RPW + r;
+            cur[r] = end[r] = 0;
+            if (row < rows) {
+                cur[r] = wave_uniform(rowptr[row]);
+                end[r] = wave_uniform(rowptr[row + 1]);
+            }
+        }
+        // NBUF window buffers used round-robin by the rows of this wave (RPW is a multiple of NBUF, so the buffer of a
+        // row is the same in every tile); the window of a visit is issued NBUF-1 visits ahead.
+        static_assert(RPW % W4_NBUF == 0 && W4_NBUF >= 2 && W4_NBUF <= 4, "buffer ring must divide the rows of a wave");
+        constexpr int NB = W4_NBUF, AHEAD = W4_NBUF - 1;
+        int wcb[NB];
+        double wvb[NB];
+        const int last_nz = max(nnz - 1, 0);
+#pragma unroll
+        for (int r = 0; r < AHEAD; ++r) window_issue(colidx, val, min(cur[r] + eidx, last_nz), wcb[r], wvb[r]);
+        __syncthreads(); // P
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int cb = (t - t_lo) & 1;
+            const int tile_lo = t * W2_ROWS, tile_hi = tile_lo + W2_ROWS;
+            const unsigned tile_base = (unsigned)(uintptr_t)(smem + cb * W2_TILE);
+            const unsigned lb = tile_base + (unsigned)(lane & 15) * 16u;
+            const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+            // one visit per row, written as a generic lambda over a compile-time row index so that every register
+            // array index below is a constant (a plain unrolled loop was left rolled by the optimiser)
+            auto visit = [&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                // issue the window of the visit AHEAD positions later (wrapping into the next tile: that row's cursor
+                // was already advanced in this tile)
+                constexpr int rn = (r + AHEAD) % RPW;
+                window_issue(colidx, val, min(cur[rn] + eidx, last_nz), wcb[rn % NB], wvb[rn % NB]);
+                // this row's window was issued AHEAD visits ago: only the AHEAD younger windows may still be in flight
+                window_wait<2 * AHEAD>(wcb[r % NB], wvb[r % NB]);
+                int wc = wcb[r % NB];
+                double wv = wvb[r % NB];
+                for (;;) {
+                    const int cnt = min(WIN, end[r] - cur[r]);
+                    if (cnt <= 0) break;
+                    const unsigned long long m = __ballot(eidx < cnt && wc < tile_hi);
+                    const int take = wave_uniform((int)__popcll(m));
+                    if (take == 0) break;
+                    const bool on = eidx < take;
+                    // the consumed set must be the first `take` window entries and lie inside this tile
+                    if (m != __ballot(on) || __ballot(on && wc < tile_lo) != 0ull) {
+                        bad = 1;
+                        cur[r] = end[r]; // park the row; the panel will be recomputed
+                        break;
+                    }
+                    {
+                        const unsigned co = on ? ((unsigned)(wc - tile_lo) << 9) : zero_rel;
+                        const double gv = on ? wv : 0.0;
+                        const int npairs = (take + 7) >> 3;
+                        double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
+                        SBLAS_QPAIR(0, 1)
+                        SBLAS_QPAIR(2, 3)
+                        SBLAS_QPAIR(4, 5)
+                        SBLAS_QPAIR(6, 7)
+                        SBLAS_QPAIR(8, 9)
+                        SBLAS_QPAIR(10, 11)
+                        SBLAS_QPAIR(12, 13)
+                        SBLAS_QPAIR(14, 15)
+                        acc[r][0] = q0;
+                        acc[r][1] = q1;
+                        acc[r][2] = q2;
+                        acc[r][3] = q3;
+                    }
+                    cur[r] += take;
+                    if (take < cnt || cur[r] >= end[r]) break; // the rest of the window is for later tiles
+                    // the whole window fell into this tile: fetch the next one now (rare: > 64 nonzeros of a row in
+                    // one 128-column tile)
+                    window_issue(colidx, val, min(cur[r] + eidx, last_nz), wc, wv);
+                    window_wait<0>(wc, wv);
+                }
+            };
+            visit(std::integral_constant<int, 0>{});
+            visit(std::integral_constant<int, 1>{});
+            if constexpr (RPW > 2) visit(std::integral_constant<int, 2 % RPW>{});
+            if constexpr (RPW > 3) visit(std::integral_constant<int, 3 % RPW>{});
+            if constexpr (RPW > 4) {
+                visit(std::integral_constant<int, 4 % RPW>{});
+                visit(std::integral_constant<int, 5 % RPW>{});
+            }
+            if constexpr (RPW > 6) {
+                visit(std::integral_constant<int, 6 % RPW>{});
+                visit(std::integral_constant<int, 7 % RPW>{});
+            }
+            __syncthreads(); // E_t
+        }
+        window_wait<0>(wcb[0], wvb[0]); // retire the last (unused) prefetches before the registers are reused
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            if (cur[r] < end[r]) bad = 1; // unconsumed nonzeros
+        if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+        __syncthreads(); // V
+        if (sm_i[0] != 0) {
+            // recompute straight from L2, one column per lane, and store in the quad accumulator layout's slot 0
+            const unsigned lane_off = (unsigned)(col0 + lane);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = row0 + wave * RPW + r;
+                int a = 0, b = 0;
+                if (row < rows) {
+                    a = wave_uniform(rowptr[row]);
+                    b = wave_uniform(rowptr[row + 1]);
+                }
+                acc[r][0] = row_direct(colidx, val, Bt, ld32, lane_off, lane, a, b);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double x = acc[r][j];
+                    x += __shfl_xor(x, 16, WAVE);
+                    x += __shfl_xor(x, 32, WAVE);
+                    acc[r][j] = x;
+                }
+        }
+    }
+    const bool fell_back = sm_i[0] != 0;
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
+
+    double *ctile = smem;
+    if (!loader) {
+        if (fell_back) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) ctile[lane * (R + 1) + wave * RPW + r] = acc[r][0];
+        } else if (lane < 16) {
+            const int jj = lane;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int rr = wave * RPW + r;
+                ctile[(2 * jj) * (R + 1) + rr] = acc[r][0];
+                ctile[(2 * jj + 1) * (R + 1) + rr] = acc[r][1];
+                ctile[(32 + 2 * jj) * (R + 1) + rr] = acc[r][2];
+                ctile[(33 + 2 * jj) * (R + 1) + rr] = acc[r][3];
+            }
+        }
+    }
+    __syncthreads(); // F
+    const int nrows = min(R, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * R; idx += 1024) {
+        const int r = idx % R, j = idx / R;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (R + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 2, direct form with DPP broadcast (any matrix; no assumption on column order or locality).
 //
 // A wave owns a row and a 128-column tile of C: every lane holds TWO adjacent columns, so a Bt row segment
@@ -1576,20 +1847,21 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
         if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO || variant == SPMM_VARIANT_WINDOW2 ||
-            variant == SPMM_VARIANT_WINDOW3) {
+            variant == SPMM_VARIANT_WINDOW3 || variant == SPMM_VARIANT_WINDOW4) {
             const int2 *info = nullptr;
             int info_rows = 1;
             if (variant != SPMM_VARIANT_DIRECT_DPP) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
-                info_rows = gen2 ? W2_PANEL : W3_PANEL;
+                const bool gen4 = (variant == SPMM_VARIANT_WINDOW4 || variant == SPMM_VARIANT_AUTO);
+                info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : W3_PANEL;
                 int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
                 const int np = (rows + info_rows - 1) / info_rows;
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
-                                   np, info_rows, rowptr, colidx, ch * 64, 1.0f, winfo);
+                                   np, info_rows, rowptr, colidx, gen4 ? 0x7fffffff : ch * 64, 1.0f, winfo);
                 dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
                 const char *ab = getenv("SBLAS_ABLATE"); /* diagnostics only: wrong results when set */
                 const int ablate = ab ? atoi(ab) : 0;
@@ -1601,7 +1873,12 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
-                if (gen2) {
+                if (gen4) {
+                    (void)hipFuncSetAttribute((const void *)spmm_window4_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
+                    hipLaunchKernelGGL(spmm_window4_kernel, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
+                                       colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, ablate, (int)nnz);
+                } else if (gen2) {
                     if (ch == 1) SBLAS_W_LAUNCH(spmm_window2_kernel, 1);
                     else if (ch == 2) SBLAS_W_LAUNCH(spmm_window2_kernel, 2);
                     else if (ch == 4) SBLAS_W_LAUNCH(spmm_window2_kernel, 4);
