@@ -871,6 +871,53 @@ constexpr int W3_PANEL = W2_NCONS * W3_RPW; // 36 rows
                  : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
                  : "memory", "v110", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119")
 
+// four steps (sixteen nonzeros) in one statement: all eight 16-byte LDS reads are in flight before the first FMA, so a
+// typical visit (<= 16 nonzeros of a row in a 128-column tile) pays ONE LDS round trip.  Scratch v92..v127.
+#define SBLAS_QSTEP4(K0, K1, K2, K3)                                                                                 \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp v92, %[co], %[lb] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v93, %[co], %[lb] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v94, %[co], %[lb] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v95, %[co], %[lb] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "s_nop 0\n\t"                                                                                       \
+                 "ds_read_b128 v[96:99], v92\n\t"                                                                    \
+                 "ds_read_b128 v[100:103], v92 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[104:107], v93\n\t"                                                                  \
+                 "ds_read_b128 v[108:111], v93 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[112:115], v94\n\t"                                                                  \
+                 "ds_read_b128 v[116:119], v94 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[120:123], v95\n\t"                                                                  \
+                 "ds_read_b128 v[124:127], v95 offset:256\n\t"                                                       \
+                 "s_waitcnt lgkmcnt(7)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[96:97] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"         \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[98:99] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"         \
+                 "s_waitcnt lgkmcnt(6)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[100:101] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[102:103] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(5)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[104:105] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[106:107] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(4)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[108:109] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[110:111] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[112:113] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[114:115] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[116:117] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[118:119] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[120:121] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[122:123] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[124:125] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[126:127] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 : [c0] "+v"(q0), [c1] "+v"(q1), [c2] "+v"(q2), [c3] "+v"(q3)                                        \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+                   "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
+                   "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+
 // steps come in pairs; a pair whose second step lies past the end runs it on masked slots (value 0, zero row)
 #define SBLAS_QPAIR(K0, K1)                                                                                          \
     if (npairs > (K0 / 2)) {                                                                                         \
@@ -1168,11 +1215,13 @@ constexpr int W4_NBUF = 4;                  // window buffers: the window of a v
 __device__ __forceinline__ void window_issue(const int *__restrict__ colidx, const double *__restrict__ val, int idx,
                                              int &c, double &v)
 {
-    const int *pc = colidx + idx;
+    // scalar array base + 32-bit per-lane byte offset (idx < 2^31 / 8 is guaranteed by the int32 CSR API only for the
+    // col_idx stream; the val offset needs 33 bits in the worst case, so it keeps a 64-bit address)
+    const unsigned off4 = (unsigned)idx << 2;
     const double *pv = val + idx;
-    asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dwordx2 %1, %4, off"
                  : "=&v"(c), "=&v"(v)
-                 : "v"(pc), "v"(pv)
+                 : "v"(off4), "s"(colidx), "v"(pv)
                  : "memory");
 }
 // wait until at most `NEWER` younger vector-memory operations are outstanding
@@ -1221,35 +1270,31 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
         for (int j = 0; j < 4; ++j) acc[r][j] = 0.0;
 
     if (loader) {
-        const int ltid = tid - W2_NCONS * 64;
-        double2 st[16];
-        auto fetch = [&](int t) {
+        // ---------------- loader waves: LDS-DMA, no staging registers ----------------
+        // tools/tile_load_bench.hip: four waves staging through registers move 14 B/clk/CU from L2, four waves issuing
+        // global_load_lds_dwordx4 move 40 B/clk/CU.  Piece q (16 bytes) of a tile lives at LDS byte q*16 and comes from
+        // Bt row t*128 + q/32, bytes (q%32)*16; a wave-level DMA writes 64 consecutive pieces (wave-uniform LDS base +
+        // lane*16), so loader wave w issues pieces 64*w + 256*i + lane, i = 0..15.  Rows past the end of B are clamped
+        // to row `cols`, the all-zero row of the workspace.
+        const int lw = wave - W2_NCONS;
+        const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
+        const unsigned ldb8 = ld32 * 8u;
+        const char *bt_bytes = reinterpret_cast<const char *>(Bt);
+        auto dma_tile = [&](int t, int buf) {
+            const int r_first = t * W2_ROWS + lw * 2 + (lane >> 5);
+            char *lds_wave = reinterpret_cast<char *>(smem + buf * W2_TILE) + lw * 1024;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int q = ltid + 256 * i;
-                const int brow = t * W2_ROWS + (q >> 5);
-                double2 x = make_double2(0.0, 0.0);
-                if (brow < cols)
-                    x = *reinterpret_cast<const double2 *>(Bt + (size_t)((unsigned)brow * ld32) + col0 + ((q & 31) << 1));
-                st[i] = x;
+                const unsigned brow = (unsigned)min(r_first + 8 * i, cols);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(bt_bytes + (size_t)(brow * ldb8 + piece_off)),
+                    (__attribute__((address_space(3))) void *)(lds_wave + i * 4096), 16, 0, 0);
             }
         };
-        auto put = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int q = ltid + 256 * i;
-                *reinterpret_cast<double2 *>(smem + buf * W2_TILE + (q << 1)) = st[i];
-            }
-        };
-        fetch(t_lo);
-        put(0);
-        if (t_lo < t_hi) fetch(t_lo + 1);
-        __syncthreads(); // P
+        dma_tile(t_lo, 0);
+        __syncthreads(); // P (the barrier drains the DMA: vmcnt(0))
         for (int t = t_lo; t <= t_hi; ++t) {
-            if (t < t_hi) {
-                put(((t - t_lo) & 1) ^ 1);
-                if (t + 1 < t_hi) fetch(t + 2);
-            }
+            if (t < t_hi) dma_tile(t + 1, ((t - t_lo) & 1) ^ 1); // that buffer was last read before the previous barrier
             __syncthreads(); // E_t
         }
         __syncthreads(); // V
@@ -1297,34 +1342,38 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                 for (;;) {
                     const int cnt = min(WIN, end[r] - cur[r]);
                     if (cnt <= 0) break;
-                    const unsigned long long m = __ballot(eidx < cnt && wc < tile_hi);
-                    const int take = wave_uniform((int)__popcll(m));
-                    if (take == 0) break;
+                    // The lanes decide for themselves which window entries belong to this tile, and the first sixteen
+                    // slots are processed straight away (masked slots: value 0, zero row) -- no scalar round trip
+                    // (ballot -> popcount -> branch) sits in front of the LDS reads.  Count, validation and the rare
+                    // 17th+ nonzero follow.
+                    const bool in_tile = eidx < cnt && wc < tile_hi && wc >= tile_lo;
+                    const unsigned co = in_tile ? ((unsigned)(wc - tile_lo) << 9) : zero_rel;
+                    const double gv = in_tile ? wv : 0.0;
+                    double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
+                    SBLAS_QSTEP4(0, 1, 2, 3);
+                    const int take = wave_uniform((int)__popcll(__builtin_amdgcn_ballot_w64(eidx < cnt && wc < tile_hi)));
                     const bool on = eidx < take;
-                    // the consumed set must be the first `take` window entries and lie inside this tile
-                    if (m != __ballot(on) || __ballot(on && wc < tile_lo) != 0ull) {
+                    // the entries below tile_hi must be the first `take` window entries and none may lie below tile_lo;
+                    // otherwise the panel is recomputed (what was just accumulated is discarded with it)
+                    if (__builtin_amdgcn_ballot_w64((eidx < cnt && wc < tile_hi) != on || (on && wc < tile_lo)) != 0ull) {
                         bad = 1;
-                        cur[r] = end[r]; // park the row; the panel will be recomputed
+                        cur[r] = end[r];
                         break;
                     }
-                    {
-                        const unsigned co = on ? ((unsigned)(wc - tile_lo) << 9) : zero_rel;
-                        const double gv = on ? wv : 0.0;
+                    if (take > 16) {
                         const int npairs = (take + 7) >> 3;
-                        double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
-                        SBLAS_QPAIR(0, 1)
-                        SBLAS_QPAIR(2, 3)
                         SBLAS_QPAIR(4, 5)
                         SBLAS_QPAIR(6, 7)
                         SBLAS_QPAIR(8, 9)
                         SBLAS_QPAIR(10, 11)
                         SBLAS_QPAIR(12, 13)
                         SBLAS_QPAIR(14, 15)
-                        acc[r][0] = q0;
-                        acc[r][1] = q1;
-                        acc[r][2] = q2;
-                        acc[r][3] = q3;
                     }
+                    acc[r][0] = q0;
+                    acc[r][1] = q1;
+                    acc[r][2] = q2;
+                    acc[r][3] = q3;
+                    if (take == 0) break;
                     cur[r] += take;
                     if (take < cnt || cur[r] >= end[r]) break; // the rest of the window is for later tiles
                     // the whole window fell into this tile: fetch the next one now (rare: > 64 nonzeros of a row in
