@@ -1212,17 +1212,59 @@ constexpr int W4_NBUF = 4;                  // window buffers: the window of a v
 // a counted wait that names their destinations, so no compiler-generated use can be scheduled before the data has
 // landed (cdna_hip_programming.md section 5.7, form (ii)).  Indices are clamped instead of predicated; entries past
 // the row end are ignored by the caller (every use is masked by the window count).
-__device__ __forceinline__ void window_issue(const int *__restrict__ colidx, const double *__restrict__ val, int idx,
-                                             int &c, double &v)
+typedef int sblas_rsrc_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0) over `bytes` bytes at `p`: reads past the end return 0 instead of faulting
+__device__ __forceinline__ sblas_rsrc_t make_rsrc(const void *p, unsigned bytes)
 {
-    // scalar array base + 32-bit per-lane byte offset (idx < 2^31 / 8 is guaranteed by the int32 CSR API only for the
-    // col_idx stream; the val offset needs 33 bits in the worst case, so it keeps a 64-bit address)
-    const unsigned off4 = (unsigned)idx << 2;
-    const double *pv = val + idx;
-    asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dwordx2 %1, %4, off"
+    const unsigned long long a = (unsigned long long)p;
+    sblas_rsrc_t r;
+    r.x = (int)(unsigned)a;
+    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
+    r.z = (int)bytes;
+    r.w = 0x00020000;
+    return r;
+}
+// The window of a row = `cnt` entries at its cursor.  The cursor goes into the (scalar) buffer descriptors and the
+// lane's entry number into constant per-lane byte offsets, so issuing a window costs no vector ALU work at all;
+// lanes past `cnt` read nothing and receive 0 (their use is masked by the count anyway).
+__device__ __forceinline__ void window_issue(const int *__restrict__ colidx, const double *__restrict__ val, int cur,
+                                             int cnt, unsigned eoff4, unsigned eoff8, int &c, double &v)
+{
+    const unsigned n = (unsigned)cnt; // callers keep cur <= end, so cnt >= 0 (all scalar arithmetic)
+    const sblas_rsrc_t rc = make_rsrc(colidx + cur, n * 4u);
+    const sblas_rsrc_t rv = make_rsrc(val + cur, n * 8u);
+    asm volatile("buffer_load_dword %0, %2, %3, 0 offen\n\tbuffer_load_dwordx2 %1, %4, %5, 0 offen"
                  : "=&v"(c), "=&v"(v)
-                 : "v"(off4), "s"(colidx), "v"(pv)
+                 : "v"(eoff4), "s"(rc), "v"(eoff8), "s"(rv)
                  : "memory");
+}
+// Which window entries belong to the tile [tile_lo, tile_lo + 128)?  For those: LDS byte offset of their B row and
+// their value; for all others the offset of the all-zero row and value 0.  `m` = lane mask of the entries taken.
+// Seven vector instructions, written out because the compiler's version needs fourteen.
+__device__ __forceinline__ void window_select(int wc, double wv, int tile_lo, int cnt, int eidx, unsigned zero_rel,
+                                              unsigned &co, double &gv, unsigned long long &m)
+{
+    int glo, ghi;
+    asm volatile("v_subrev_u32 %[co], %[tlo], %[wc]\n\t"
+                 "v_cmp_gt_i32 %[m], %[cnt], %[eidx]\n\t"
+                 "v_cmp_gt_u32 vcc, 0x80, %[co]\n\t"
+                 "v_lshlrev_b32 %[co], 9, %[co]\n\t"
+                 "s_and_b64 vcc, vcc, %[m]\n\t"
+                 "s_mov_b64 %[m], vcc\n\t"
+                 "v_cndmask_b32 %[co], %[zr], %[co], vcc\n\t"
+                 "v_cndmask_b32 %[glo], 0, %[vlo], vcc\n\t"
+                 "v_cndmask_b32 %[ghi], 0, %[vhi], vcc"
+                 : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
+                 : [tlo] "s"(tile_lo), [wc] "v"(wc), [cnt] "s"(cnt), [eidx] "v"(eidx), [zr] "v"(zero_rel),
+                   [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv))
+                 : "vcc");
+    gv = __hiloint2double(ghi, glo);
+}
+__device__ __forceinline__ int mask_count(unsigned long long m)
+{
+    int n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
 }
 // wait until at most `NEWER` younger vector-memory operations are outstanding
 template <int NEWER> __device__ __forceinline__ void window_wait(int &c, double &v)
@@ -1300,8 +1342,10 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
         __syncthreads(); // V
     } else {
         const int eidx = ((lane & 15) << 2) + (lane >> 4); // window entry held by this lane (quad order)
+        const unsigned eoff4 = (unsigned)eidx * 4u, eoff8 = (unsigned)eidx * 8u;
         int cur[RPW], end[RPW];
         int bad = 0;
+        unsigned long long viol = 0ull; // lanes whose entry broke the "consumed set = window prefix" expectation
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int row = row0 + wave * RPW + r;
@@ -1317,13 +1361,13 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
         constexpr int NB = W4_NBUF, AHEAD = W4_NBUF - 1;
         int wcb[NB];
         double wvb[NB];
-        const int last_nz = max(nnz - 1, 0);
 #pragma unroll
-        for (int r = 0; r < AHEAD; ++r) window_issue(colidx, val, min(cur[r] + eidx, last_nz), wcb[r], wvb[r]);
+        for (int r = 0; r < AHEAD; ++r)
+            window_issue(colidx, val, cur[r], min(WIN, end[r] - cur[r]), eoff4, eoff8, wcb[r], wvb[r]);
         __syncthreads(); // P
         for (int t = t_lo; t <= t_hi; ++t) {
             const int cb = (t - t_lo) & 1;
-            const int tile_lo = t * W2_ROWS, tile_hi = tile_lo + W2_ROWS;
+            const int tile_lo = t * W2_ROWS;
             const unsigned tile_base = (unsigned)(uintptr_t)(smem + cb * W2_TILE);
             const unsigned lb = tile_base + (unsigned)(lane & 15) * 16u;
             const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
@@ -1334,11 +1378,13 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                 // issue the window of the visit AHEAD positions later (wrapping into the next tile: that row's cursor
                 // was already advanced in this tile)
                 constexpr int rn = (r + AHEAD) % RPW;
-                window_issue(colidx, val, min(cur[rn] + eidx, last_nz), wcb[rn % NB], wvb[rn % NB]);
+                window_issue(colidx, val, cur[rn], min(WIN, end[rn] - cur[rn]), eoff4, eoff8, wcb[rn % NB],
+                             wvb[rn % NB]);
                 // this row's window was issued AHEAD visits ago: only the AHEAD younger windows may still be in flight
                 window_wait<2 * AHEAD>(wcb[r % NB], wvb[r % NB]);
                 int wc = wcb[r % NB];
                 double wv = wvb[r % NB];
+                double &q0 = acc[r][0], &q1 = acc[r][1], &q2 = acc[r][2], &q3 = acc[r][3];
                 for (;;) {
                     const int cnt = min(WIN, end[r] - cur[r]);
                     if (cnt <= 0) break;
@@ -1346,20 +1392,17 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                     // slots are processed straight away (masked slots: value 0, zero row) -- no scalar round trip
                     // (ballot -> popcount -> branch) sits in front of the LDS reads.  Count, validation and the rare
                     // 17th+ nonzero follow.
-                    const bool in_tile = eidx < cnt && wc < tile_hi && wc >= tile_lo;
-                    const unsigned co = in_tile ? ((unsigned)(wc - tile_lo) << 9) : zero_rel;
-                    const double gv = in_tile ? wv : 0.0;
-                    double q0 = acc[r][0], q1 = acc[r][1], q2 = acc[r][2], q3 = acc[r][3];
+                    static_assert(W2_ROWS == 128, "window_select compares against a 128-row tile");
+                    unsigned co;
+                    double gv;
+                    unsigned long long m;
+                    window_select(wc, wv, tile_lo, cnt, eidx, zero_rel, co, gv, m);
                     SBLAS_QSTEP4(0, 1, 2, 3);
-                    const int take = wave_uniform((int)__popcll(__builtin_amdgcn_ballot_w64(eidx < cnt && wc < tile_hi)));
-                    const bool on = eidx < take;
-                    // the entries below tile_hi must be the first `take` window entries and none may lie below tile_lo;
-                    // otherwise the panel is recomputed (what was just accumulated is discarded with it)
-                    if (__builtin_amdgcn_ballot_w64((eidx < cnt && wc < tile_hi) != on || (on && wc < tile_lo)) != 0ull) {
-                        bad = 1;
-                        cur[r] = end[r];
-                        break;
-                    }
+                    const int take = mask_count(m);
+                    // with ascending columns the entries of this tile are exactly the first `take` of the window; any
+                    // other pattern is remembered and the panel recomputed at the end (the loop itself stays safe:
+                    // masked slots read the zero row, the cursor never passes the row end)
+                    viol |= m ^ __builtin_amdgcn_ballot_w64(eidx < take);
                     if (take > 16) {
                         const int npairs = (take + 7) >> 3;
                         SBLAS_QPAIR(4, 5)
@@ -1369,16 +1412,11 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                         SBLAS_QPAIR(12, 13)
                         SBLAS_QPAIR(14, 15)
                     }
-                    acc[r][0] = q0;
-                    acc[r][1] = q1;
-                    acc[r][2] = q2;
-                    acc[r][3] = q3;
-                    if (take == 0) break;
                     cur[r] += take;
                     if (take < cnt || cur[r] >= end[r]) break; // the rest of the window is for later tiles
-                    // the whole window fell into this tile: fetch the next one now (rare: > 64 nonzeros of a row in
+                    // the whole window fell into this tile: fetch the next one now (rare: > 32 nonzeros of a row in
                     // one 128-column tile)
-                    window_issue(colidx, val, min(cur[r] + eidx, last_nz), wc, wv);
+                    window_issue(colidx, val, cur[r], min(WIN, end[r] - cur[r]), eoff4, eoff8, wc, wv);
                     window_wait<0>(wc, wv);
                 }
             };
@@ -1397,6 +1435,7 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
             __syncthreads(); // E_t
         }
         window_wait<0>(wcb[0], wvb[0]); // retire the last (unused) prefetches before the registers are reused
+        if (viol != 0ull) bad = 1;
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
             if (cur[r] < end[r]) bad = 1; // unconsumed nonzeros
