@@ -554,7 +554,8 @@ constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64
 __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
                                                              const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx, int max_row_len,
-                                                             float min_density, int2 *__restrict__ info)
+                                                             float min_density, int2 *__restrict__ info,
+                                                             int exclude_tail)
 {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -578,7 +579,10 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         mlen = max(mlen, __shfl_xor(mlen, m, WAVE));
     }
     if (lane == 0) {
-        const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len &&
+        // exclude_tail: the panel that holds the very last nonzero goes to the direct kernel (fifth generation: its
+        // col_idx fetch is eight bytes wide and must not run past the end of the array)
+        const bool tail = exclude_tail && rowptr[min((p + 1) * panel_rows, rows)] == rowptr[rows];
+        const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len && !tail &&
                         (float)nnz >= min_density * (float)(last - first + 1);
         info[p] = ok ? make_int2(first, last) : make_int2(1, 0);
     }
@@ -1206,36 +1210,33 @@ __global__ __launch_bounds__(1024) void spmm_window3_kernel(
 constexpr int W4_RPW = 4;
 constexpr int W4_PANEL = W2_NCONS * W4_RPW; // rows per panel
 constexpr int W4_NBUF = 4;                  // window buffers: the window of a visit is issued NBUF-1 visits ahead
+constexpr int W4_PF_DIST = 32;              // A prefetch: first entry touched, counted from the row's cursor
 
-// Window loads of the streaming consumer, hidden from hipcc's vmcnt bookkeeping (which turns conservative in the
-// visit loop and would wait for the prefetch just issued): the loads are issued in one asm statement and retired by
-// a counted wait that names their destinations, so no compiler-generated use can be scheduled before the data has
-// landed (cdna_hip_programming.md section 5.7, form (ii)).  Indices are clamped instead of predicated; entries past
-// the row end are ignored by the caller (every use is masked by the window count).
+// Window loads of the streaming consumer.  They are buffer loads through two structured descriptors (col_idx:
+// stride 4, val: stride 8) that start at the first nonzero of the wave's rows: the per-lane operand is just the
+// entry number (cursor + lane's window slot, ONE vector add per window), entries past the end of the arrays read 0
+// instead of faulting, and no address arithmetic is left in the visit loop.  The loads are hidden from hipcc's vmcnt
+// bookkeeping (which turns conservative in the visit loop and would wait for the prefetch just issued): issued in
+// one asm statement and retired by a counted wait that names their destinations, so no compiler-generated use can
+// be scheduled before the data has landed (cdna_hip_programming.md section 5.7, form (ii)).  Entries past the row end
+// are ignored by the caller (every use is masked by the window count).
 typedef int sblas_rsrc_t __attribute__((ext_vector_type(4)));
-// raw buffer descriptor (stride 0) over `bytes` bytes at `p`: reads past the end return 0 instead of faulting
-__device__ __forceinline__ sblas_rsrc_t make_rsrc(const void *p, unsigned bytes)
+__device__ __forceinline__ sblas_rsrc_t make_rsrc(const void *p, unsigned stride, unsigned records)
 {
     const unsigned long long a = (unsigned long long)p;
     sblas_rsrc_t r;
     r.x = (int)(unsigned)a;
-    r.y = (int)((unsigned)(a >> 32) & 0xffffu);
-    r.z = (int)bytes;
+    r.y = (int)(((unsigned)(a >> 32) & 0xffffu) | (stride << 16));
+    r.z = (int)records;
     r.w = 0x00020000;
     return r;
 }
-// The window of a row = `cnt` entries at its cursor.  The cursor goes into the (scalar) buffer descriptors and the
-// lane's entry number into constant per-lane byte offsets, so issuing a window costs no vector ALU work at all;
-// lanes past `cnt` read nothing and receive 0 (their use is masked by the count anyway).
-__device__ __forceinline__ void window_issue(const int *__restrict__ colidx, const double *__restrict__ val, int cur,
-                                             int cnt, unsigned eoff4, unsigned eoff8, int &c, double &v)
+__device__ __forceinline__ void window_issue(sblas_rsrc_t rc, sblas_rsrc_t rv, int cur, int eidx, int &c, double &v)
 {
-    const unsigned n = (unsigned)cnt; // callers keep cur <= end, so cnt >= 0 (all scalar arithmetic)
-    const sblas_rsrc_t rc = make_rsrc(colidx + cur, n * 4u);
-    const sblas_rsrc_t rv = make_rsrc(val + cur, n * 8u);
-    asm volatile("buffer_load_dword %0, %2, %3, 0 offen\n\tbuffer_load_dwordx2 %1, %4, %5, 0 offen"
+    const int idx = cur + eidx;
+    asm volatile("buffer_load_dword %0, %2, %3, 0 idxen\n\tbuffer_load_dwordx2 %1, %2, %4, 0 idxen"
                  : "=&v"(c), "=&v"(v)
-                 : "v"(eoff4), "s"(rc), "v"(eoff8), "s"(rv)
+                 : "v"(idx), "s"(rc), "s"(rv)
                  : "memory");
 }
 // Which window entries belong to the tile [tile_lo, tile_lo + 128)?  For those: LDS byte offset of their B row and
@@ -1257,7 +1258,7 @@ __device__ __forceinline__ void window_select(int wc, double wv, int tile_lo, in
                  : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
                  : [tlo] "s"(tile_lo), [wc] "v"(wc), [cnt] "s"(cnt), [eidx] "v"(eidx), [zr] "v"(zero_rel),
                    [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv))
-                 : "vcc");
+                 : "vcc", "scc");
     gv = __hiloint2double(ghi, glo);
 }
 __device__ __forceinline__ int mask_count(unsigned long long m)
@@ -1276,6 +1277,11 @@ template <int NEWER> __device__ __forceinline__ void window_wait(int &c, double 
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(c), "+v"(v)::"memory");
 }
 
+// SBLAS_ABLATE bits understood by this kernel (diagnostics; every one of them produces wrong results):
+//   0x10000 no LDS reads / FMAs      0x20000 no tile DMA      0x40000 no per-tile barrier     0x80000 no A prefetch
+//   0x10000000 windows used without waiting (and no fallback)   0x20000000 no window loads in the tile loop
+//   0x40000000 no tile loop at all   bits 8..15: pace the DMA (64-cycle sleeps)   bits 20..27: A prefetch distance
+template <bool ABL> // ABL: the diagnostic switches are compiled in (launched only when SBLAS_ABLATE is set)
 __global__ __launch_bounds__(1024) void spmm_window4_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
@@ -1286,7 +1292,7 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
     static_assert(64 * (R + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *zero_row = smem + 2 * W2_TILE;
-    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad, [8..8+R) = published row cursors
 
     const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
     const int2 span = info[panel];
@@ -1298,9 +1304,9 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
     const int row0 = panel * R;
     const int col0 = blockIdx.y * 64;
     const unsigned ld32 = (unsigned)ldbt;
-    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const int t_lo = span.x / W2_ROWS, t_hi = (ABL && (ablate & 0x40000000)) ? t_lo - 1 : span.y / W2_ROWS;
     const bool loader = wave >= W2_NCONS;
-    (void)ablate;
+    const bool no_bar = ABL && (ablate & 0x40000) != 0;
 
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
@@ -1322,6 +1328,8 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
         const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
         const unsigned ldb8 = ld32 * 8u;
         const char *bt_bytes = reinterpret_cast<const char *>(Bt);
+        const int pace = ABL ? (ablate >> 8) & 0xff : 0;
+        const bool no_dma = ABL && (ablate & 0x20000) != 0;
         auto dma_tile = [&](int t, int buf) {
             const int r_first = t * W2_ROWS + lw * 2 + (lane >> 5);
             char *lds_wave = reinterpret_cast<char *>(smem + buf * W2_TILE) + lw * 1024;
@@ -1331,18 +1339,60 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(bt_bytes + (size_t)(brow * ldb8 + piece_off)),
                     (__attribute__((address_space(3))) void *)(lds_wave + i * 4096), 16, 0, 0);
+                if ((i & 1) == 1)
+                    for (int z = 0; z < pace; ++z) __builtin_amdgcn_s_sleep(1);
             }
         };
+        // A prefetch: the loader waves touch the col_idx/val cache lines a little ahead of every row's cursor
+        // (published by the consumers once per tile) so that the consumers' window loads find them in L2: five lanes
+        // per row -- two col_idx lines, three val lines, 48 entries starting pf_dist entries past the cursor.  The
+        // touch is issued after the tile DMA and never waited for (counted vmcnt), so HBM latency stays off the
+        // barrier path.  Worth 3 % on the bench matrix.
+        static_assert(R == 4 * 12, "prefetch lanes: 12 rows per loader wave, 5 lanes per row");
+        const int pf_dist = (ABL && ((ablate >> 20) & 0xff)) ? ((ablate >> 20) & 0xff) : W4_PF_DIST;
+        const bool no_pf = ABL && (ablate & 0x80000) != 0;
+        const int prow = min(lw * 12 + lane / 5, R - 1);
+        const int pk = lane % 5;
+        const int p_off = pf_dist + (pk < 2 ? 32 * pk : 16 * (pk - 2));
+        const int p_last = max(rowptr[min(row0 + prow, rows - 1) + 1] - 1, 0);
+        const char *p_base = pk < 2 ? reinterpret_cast<const char *>(colidx) : reinterpret_cast<const char *>(val);
+        const int p_shift = pk < 2 ? 2 : 3;
+        int pf_sink = 0; // landing register of the touches: read-write in every statement below so that the register
+                         // allocator never lends it to another value while a touch is still in flight
+        auto touch = [&](int cursor) {
+            const int idx = min(cursor + p_off, p_last);
+            const char *p = p_base + ((size_t)(unsigned)idx << p_shift);
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(p) : "memory");
+        };
         dma_tile(t_lo, 0);
-        __syncthreads(); // P (the barrier drains the DMA: vmcnt(0))
+        __syncthreads(); // P (the barrier drains the DMA: vmcnt(0)); the consumers have published the row starts
         for (int t = t_lo; t <= t_hi; ++t) {
-            if (t < t_hi) dma_tile(t + 1, ((t - t_lo) & 1) ^ 1); // that buffer was last read before the previous barrier
-            __syncthreads(); // E_t
+            const int cursor = sm_i[8 + prow]; // as of the end of the previous tile
+            if (t < t_hi && !no_dma) dma_tile(t + 1, ((t - t_lo) & 1) ^ 1); // that buffer was last read before the previous barrier
+            if (!no_pf) {
+                touch(cursor);
+                // everything but the touch just issued has landed: the tile DMA and the previous tile's touch
+                asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            }
+            if (!no_bar) {
+                if (no_pf) __syncthreads(); // E_t
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // E_t, without draining the touch
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink)::"memory");
         __syncthreads(); // V
     } else {
         const int eidx = ((lane & 15) << 2) + (lane >> 4); // window entry held by this lane (quad order)
-        const unsigned eoff4 = (unsigned)eidx * 4u, eoff8 = (unsigned)eidx * 8u;
+        // entry number used for the loads: the lanes past the window size get an index that no descriptor covers, so
+        // they cost no memory traffic (and read 0)
+        const int eload = eidx < WIN ? eidx : 0x40000000;
+        const bool no_math = ABL && (ablate & 0x10000) != 0, no_wait = ABL && (ablate & 0x10000000) != 0;
+        const bool no_issue = ABL && (ablate & 0x20000000) != 0;
+        // cursors are kept relative to the first nonzero of the wave's rows (base of the two descriptors)
+        const int wrow = min(row0 + wave * RPW, rows);
+        const int wstart = wave_uniform(rowptr[wrow]);
+        const sblas_rsrc_t rc = make_rsrc(colidx + wstart, 4u, (unsigned)(nnz - wstart));
+        const sblas_rsrc_t rv = make_rsrc(val + wstart, 8u, (unsigned)(nnz - wstart));
         int cur[RPW], end[RPW];
         int bad = 0;
         unsigned long long viol = 0ull; // lanes whose entry broke the "consumed set = window prefix" expectation
@@ -1351,8 +1401,8 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
             const int row = row0 + wave * RPW + r;
             cur[r] = end[r] = 0;
             if (row < rows) {
-                cur[r] = wave_uniform(rowptr[row]);
-                end[r] = wave_uniform(rowptr[row + 1]);
+                cur[r] = wave_uniform(rowptr[row]) - wstart;
+                end[r] = wave_uniform(rowptr[row + 1]) - wstart;
             }
         }
         // NBUF window buffers used round-robin by the rows of this wave (RPW is a multiple of NBUF, so the buffer of a
@@ -1362,8 +1412,10 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
         int wcb[NB];
         double wvb[NB];
 #pragma unroll
-        for (int r = 0; r < AHEAD; ++r)
-            window_issue(colidx, val, cur[r], min(WIN, end[r] - cur[r]), eoff4, eoff8, wcb[r], wvb[r]);
+        for (int r = 0; r < AHEAD; ++r) window_issue(rc, rv, cur[r], eload, wcb[r], wvb[r]);
+        static_assert(RPW == 4, "the cursors of a wave are published as one int4");
+        int4 *cur_pub = reinterpret_cast<int4 *>(sm_i + 8) + wave; // read by the loader waves' prefetch (absolute)
+        if (lane == 0) *cur_pub = make_int4(cur[0] + wstart, cur[1] + wstart, cur[2] + wstart, cur[3] + wstart);
         __syncthreads(); // P
         for (int t = t_lo; t <= t_hi; ++t) {
             const int cb = (t - t_lo) & 1;
@@ -1373,72 +1425,73 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
             const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
             // one visit per row, written as a generic lambda over a compile-time row index so that every register
             // array index below is a constant (a plain unrolled loop was left rolled by the optimiser)
-            auto visit = [&](auto rc) {
-                constexpr int r = decltype(rc)::value;
+            auto visit = [&](auto rc_) {
+                constexpr int r = decltype(rc_)::value;
                 // issue the window of the visit AHEAD positions later (wrapping into the next tile: that row's cursor
                 // was already advanced in this tile)
                 constexpr int rn = (r + AHEAD) % RPW;
-                window_issue(colidx, val, cur[rn], min(WIN, end[rn] - cur[rn]), eoff4, eoff8, wcb[rn % NB],
-                             wvb[rn % NB]);
+                if (!no_issue) window_issue(rc, rv, cur[rn], eload, wcb[rn % NB], wvb[rn % NB]);
                 // this row's window was issued AHEAD visits ago: only the AHEAD younger windows may still be in flight
-                window_wait<2 * AHEAD>(wcb[r % NB], wvb[r % NB]);
+                if (!no_wait) window_wait<2 * AHEAD>(wcb[r % NB], wvb[r % NB]);
+                double &q0 = acc[r][0], &q1 = acc[r][1], &q2 = acc[r][2], &q3 = acc[r][3];
+                // The lanes decide for themselves which window entries belong to this tile, and the first sixteen slots
+                // are processed straight away (masked slots: value 0, zero row) -- no scalar round trip (ballot ->
+                // popcount -> branch) sits in front of the LDS reads, and a row that is already finished (count <= 0)
+                // simply runs on masked slots.  Count and validation follow.  One loop body serves the rare cases too
+                // (a single back edge and a single exit, so the accumulators stay in place): more than 16 entries in
+                // this tile -> drop the 16 just done by shifting the window four lanes down every DPP row and go again;
+                // whole window consumed -> fetch the next one and go again.
+                static_assert(W2_ROWS == 128, "window_select compares against a 128-row tile");
+                int cnt = min(WIN, end[r] - cur[r]);
                 int wc = wcb[r % NB];
                 double wv = wvb[r % NB];
-                double &q0 = acc[r][0], &q1 = acc[r][1], &q2 = acc[r][2], &q3 = acc[r][3];
                 for (;;) {
-                    const int cnt = min(WIN, end[r] - cur[r]);
-                    if (cnt <= 0) break;
-                    // The lanes decide for themselves which window entries belong to this tile, and the first sixteen
-                    // slots are processed straight away (masked slots: value 0, zero row) -- no scalar round trip
-                    // (ballot -> popcount -> branch) sits in front of the LDS reads.  Count, validation and the rare
-                    // 17th+ nonzero follow.
-                    static_assert(W2_ROWS == 128, "window_select compares against a 128-row tile");
                     unsigned co;
                     double gv;
                     unsigned long long m;
                     window_select(wc, wv, tile_lo, cnt, eidx, zero_rel, co, gv, m);
-                    SBLAS_QSTEP4(0, 1, 2, 3);
+                    if (!no_math) { SBLAS_QSTEP4(0, 1, 2, 3); }
                     const int take = mask_count(m);
                     // with ascending columns the entries of this tile are exactly the first `take` of the window; any
                     // other pattern is remembered and the panel recomputed at the end (the loop itself stays safe:
                     // masked slots read the zero row, the cursor never passes the row end)
                     viol |= m ^ __builtin_amdgcn_ballot_w64(eidx < take);
-                    if (take > 16) {
-                        const int npairs = (take + 7) >> 3;
-                        SBLAS_QPAIR(4, 5)
-                        SBLAS_QPAIR(6, 7)
-                        SBLAS_QPAIR(8, 9)
-                        SBLAS_QPAIR(10, 11)
-                        SBLAS_QPAIR(12, 13)
-                        SBLAS_QPAIR(14, 15)
+                    const bool more = take > 16 || (take >= cnt && cur[r] + take < end[r]);
+                    if (__builtin_expect(!more, 1)) {
+                        cur[r] += take;
+                        break;
                     }
-                    cur[r] += take;
-                    if (take < cnt || cur[r] >= end[r]) break; // the rest of the window is for later tiles
-                    // the whole window fell into this tile: fetch the next one now (rare: > 32 nonzeros of a row in
-                    // one 128-column tile)
-                    window_issue(colidx, val, cur[r], min(WIN, end[r] - cur[r]), eoff4, eoff8, wc, wv);
-                    window_wait<0>(wc, wv);
+                    if (take > 16) {
+                        cur[r] += 16;
+                        cnt -= 16;
+                        int lo = __double2loint(wv), hi = __double2hiint(wv);
+                        asm volatile("s_nop 1\n\t"
+                                     "v_mov_b32_dpp %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "v_mov_b32_dpp %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                     "v_mov_b32_dpp %2, %2 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                     : "+v"(wc), "+v"(lo), "+v"(hi));
+                        wv = __hiloint2double(hi, lo);
+                    } else {
+                        cur[r] += take;
+                        cnt = min(WIN, end[r] - cur[r]);
+                        window_issue(rc, rv, cur[r], eload, wc, wv);
+                        window_wait<0>(wc, wv);
+                    }
                 }
             };
             visit(std::integral_constant<int, 0>{});
             visit(std::integral_constant<int, 1>{});
-            if constexpr (RPW > 2) visit(std::integral_constant<int, 2 % RPW>{});
-            if constexpr (RPW > 3) visit(std::integral_constant<int, 3 % RPW>{});
-            if constexpr (RPW > 4) {
-                visit(std::integral_constant<int, 4 % RPW>{});
-                visit(std::integral_constant<int, 5 % RPW>{});
-            }
-            if constexpr (RPW > 6) {
-                visit(std::integral_constant<int, 6 % RPW>{});
-                visit(std::integral_constant<int, 7 % RPW>{});
-            }
-            __syncthreads(); // E_t
+            visit(std::integral_constant<int, 2>{});
+            visit(std::integral_constant<int, 3>{});
+            if (lane == 0) *cur_pub = make_int4(cur[0] + wstart, cur[1] + wstart, cur[2] + wstart, cur[3] + wstart);
+            if (!no_bar) __syncthreads(); // E_t
         }
         window_wait<0>(wcb[0], wvb[0]); // retire the last (unused) prefetches before the registers are reused
         if (viol != 0ull) bad = 1;
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
             if (cur[r] < end[r]) bad = 1; // unconsumed nonzeros
+        if (no_wait) bad = 0;
         if (bad && lane == 0) atomicOr(&sm_i[0], 1);
         __syncthreads(); // V
         if (sm_i[0] != 0) {
@@ -1484,6 +1537,334 @@ __global__ __launch_bounds__(1024) void spmm_window4_kernel(
                 ctile[(32 + 2 * jj) * (R + 1) + rr] = acc[r][2];
                 ctile[(33 + 2 * jj) * (R + 1) + rr] = acc[r][3];
             }
+        }
+    }
+    __syncthreads(); // F
+    const int nrows = min(R, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * R; idx += 1024) {
+        const int r = idx % R, j = idx / R;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (R + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form, fifth generation: no loader waves.
+//
+// SQ counters on the fourth generation: vector ALU 38 % busy, LDS 37 %, and a consumer wave spends ~1100 cycles on
+// a visit whose instructions would fit in ~450 -- a wave issues at most one instruction every four cycles and the
+// visit is one serial chain, so throughput is (waves that consume) / (visit latency), and a quarter of the
+// waves were loaders that sleep at the barrier.  Here all 16 waves consume (64-row panels: 25 % less tile traffic
+// per nonzero as well) and every wave issues its own 4 KB share of the next tile's LDS-DMA at the top of a tile.
+// The DMA shares the in-order vmcnt queue with the window loads, so the counted waits grow by the four DMA
+// operations (10 instead of 6) and the wait of a tile's last visit (everything older than the windows of the
+// last three visits has landed) also covers the DMA -- no extra wait in front of the barrier.  The same number of
+// vector-memory operations is issued in every tile (the last tile fetches a tile nobody reads), which keeps the
+// counts exact.
+// ---------------------------------------------------------------------------------------------
+constexpr int W5_RPW = 4;
+constexpr int W5_PANEL = 16 * W5_RPW; // 64 rows
+
+__device__ __forceinline__ void dma_rows_scalar(unsigned lds_addr, unsigned voff, const char *base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_rows_vector(unsigned lds_addr, const char *addr)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(addr)
+                 : "memory");
+}
+// One vector-memory instruction per window (the address unit is the busiest resource of this kernel: a wave64 load
+// occupies it for 16 cycles whatever it fetches).  Lanes k = 0..7 of every DPP row fetch the VALUE of window entry
+// 4k + q (q = DPP row), lanes 8..15 fetch eight bytes of col_idx starting at the same entry (the first dword is
+// used): the broadcast of step k then takes the Bt row offset from lane k + 8 and the value from lane k.
+__device__ __forceinline__ void window_issue5(const char *addr, double &d)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(d) : "v"(addr) : "memory");
+}
+template <int NEWER> __device__ __forceinline__ void window_wait5(double &d)
+{
+    static_assert(NEWER == 0 || NEWER == 3 || NEWER == 7, "counts of the fifth-generation visit loop");
+    if (NEWER == 7) asm volatile("s_waitcnt vmcnt(7)" : "+v"(d)::"memory");
+    else if (NEWER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(d)::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(d)::"memory");
+}
+constexpr unsigned long long W5_COL_LANES = 0xff00ff00ff00ff00ull, W5_VAL_LANES = 0x00ff00ff00ff00ffull;
+// tile membership of the window entries: decided on the col_idx lanes, copied eight lanes down for the value lanes.
+// co (col_idx lanes) = LDS offset of the B row or of the zero row; gv (value lanes) = value or 0; m = value lanes taken
+__device__ __forceinline__ void window_select5(double d, int tile_lo, int cnt, int eidx, unsigned zero_rel,
+                                               unsigned &co, double &gv, unsigned long long &m)
+{
+    int glo, ghi;
+    asm volatile("v_subrev_u32 %[co], %[tlo], %[d0]\n\t"
+                 "v_cmp_gt_i32 %[m], %[cnt], %[eidx]\n\t"
+                 "v_cmp_gt_u32 vcc, 0x80, %[co]\n\t"
+                 "v_lshlrev_b32 %[co], 9, %[co]\n\t"
+                 "s_and_b64 vcc, vcc, %[m]\n\t"
+                 "s_and_b64 vcc, vcc, %[cl]\n\t"
+                 "s_lshr_b64 %[m], vcc, 8\n\t"
+                 "s_or_b64 vcc, vcc, %[m]\n\t"
+                 "v_cndmask_b32 %[co], %[zr], %[co], vcc\n\t"
+                 "v_cndmask_b32 %[glo], 0, %[d0], vcc\n\t"
+                 "v_cndmask_b32 %[ghi], 0, %[d1], vcc"
+                 : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
+                 : [tlo] "s"(tile_lo), [cnt] "s"(cnt), [eidx] "v"(eidx), [zr] "v"(zero_rel), [cl] "s"(W5_COL_LANES),
+                   [d0] "v"(__double2loint(d)), [d1] "v"(__double2hiint(d))
+                 : "vcc", "scc");
+    gv = __hiloint2double(ghi, glo);
+}
+// sixteen slots: steps K0..K3, Bt row offset from lane K + 8, value from lane K of every DPP row
+#define SBLAS_QSTEP4M(K0, K1, K2, K3, C0, C1, C2, C3)                                                                \
+    asm volatile("s_nop 1\n\t"                                                                                       \
+                 "v_add_u32_dpp v92, %[co], %[lb] row_newbcast:" #C0 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v93, %[co], %[lb] row_newbcast:" #C1 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v94, %[co], %[lb] row_newbcast:" #C2 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "v_add_u32_dpp v95, %[co], %[lb] row_newbcast:" #C3 " row_mask:0xf bank_mask:0xf\n\t"               \
+                 "s_nop 0\n\t"                                                                                       \
+                 "ds_read_b128 v[96:99], v92\n\t"                                                                    \
+                 "ds_read_b128 v[100:103], v92 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[104:107], v93\n\t"                                                                  \
+                 "ds_read_b128 v[108:111], v93 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[112:115], v94\n\t"                                                                  \
+                 "ds_read_b128 v[116:119], v94 offset:256\n\t"                                                       \
+                 "ds_read_b128 v[120:123], v95\n\t"                                                                  \
+                 "ds_read_b128 v[124:127], v95 offset:256\n\t"                                                       \
+                 "s_waitcnt lgkmcnt(7)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[96:97] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"         \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[98:99] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"         \
+                 "s_waitcnt lgkmcnt(6)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[100:101] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[102:103] row_newbcast:" #K0 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(5)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[104:105] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[106:107] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(4)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[108:109] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[110:111] row_newbcast:" #K1 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(3)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[112:113] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[114:115] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(2)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[116:117] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[118:119] row_newbcast:" #K2 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(1)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c0], %[gv], v[120:121] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c1], %[gv], v[122:123] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "s_waitcnt lgkmcnt(0)\n\t"                                                                          \
+                 "v_fmac_f64_dpp %[c2], %[gv], v[124:125] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_fmac_f64_dpp %[c3], %[gv], v[126:127] row_newbcast:" #K3 " row_mask:0xf bank_mask:0xf\n\t"       \
+                 : [c0] "+v"(q0), [c1] "+v"(q1), [c2] "+v"(q2), [c3] "+v"(q3)                                        \
+                 : [co] "v"(co), [lb] "v"(lb), [gv] "v"(gv)                                                          \
+                 : "memory", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", \
+                   "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
+                   "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+
+// SBLAS_ABLATE bits understood (diagnostics, wrong results): 0x10000 no LDS reads / FMAs, 0x40000 no per-tile
+// barrier, 0x40000000 no tile loop at all.
+template <bool ABL>
+__global__ __launch_bounds__(1024) void spmm_window5_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int ablate, int nnz)
+{
+    constexpr int RPW = W5_RPW, R = W5_PANEL;
+    constexpr int WIN = 32; // window entries fetched per visit
+    static_assert(64 * (R + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zero_row = smem + 2 * W2_TILE;
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    const int2 span = info[panel];
+    if (span.x > span.y) return; // the direct kernel owns this panel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * R;
+    const int col0 = blockIdx.y * 64;
+    const unsigned ld32 = (unsigned)ldbt;
+    const int t_lo = span.x / W2_ROWS, t_hi = (ABL && (ablate & 0x40000000)) ? t_lo - 1 : span.y / W2_ROWS;
+    const bool no_bar = ABL && (ablate & 0x40000) != 0, no_math = ABL && (ablate & 0x10000) != 0;
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    double acc[RPW][4];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.0;
+
+    // ---- tile DMA: wave w moves Bt rows 8w..8w+7 of a tile (4 instructions of two rows each: lanes 0-31 the
+    // first, lanes 32-63 the second); tile row j lives at LDS byte j*512.  Rows past the end of B are clamped to row
+    // `cols`, the all-zero row of the workspace: the common case (all eight rows exist) runs on scalar addresses.
+    const unsigned ldb8 = ld32 * 8u;
+    const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
+    const unsigned pair_off = (unsigned)(lane >> 5) * ldb8 + piece_off;
+    const char *bt_bytes = reinterpret_cast<const char *>(Bt);
+    auto dma_tile = [&](int t, int buf) {
+        const int r0 = t * W2_ROWS + wave * 8;
+        const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)wave * 4096u;
+        if (r0 + 7 <= cols) {
+            const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned brow = (unsigned)min(r0 + 2 * i + (lane >> 5), cols);
+                dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off));
+            }
+        }
+    };
+
+    // window entry held by this lane (quad order; value in lanes 0-7 of a DPP row, col_idx in lanes 8-15)
+    const int eidx = ((lane & 7) << 2) + (lane >> 4);
+    const bool col_lane = (lane & 8) != 0;
+    // cursors are kept relative to the first nonzero of the wave's rows
+    const int wrow = min(row0 + wave * RPW, rows);
+    const int wstart = wave_uniform(rowptr[wrow]);
+    // loads are clamped to the arrays (clamped entries lie past `cnt`).  A col_idx lane fetches eight bytes, so it is
+    // clamped one entry lower: the very last nonzero of the matrix would then read its neighbour's column -- the
+    // classifier hands the panel that contains it to the direct kernel (`exclude_tail`).
+    const int last_rel = max(nnz - (col_lane ? 2 : 1) - wstart, 0);
+    const char *lane_base = col_lane ? reinterpret_cast<const char *>(colidx + wstart)
+                                     : reinterpret_cast<const char *>(val + wstart);
+    const int lane_shift = col_lane ? 2 : 3;
+    auto win_addr = [&](int cursor) {
+        const int idx = min(cursor + eidx, last_rel);
+        return lane_base + ((size_t)(unsigned)idx << lane_shift);
+    };
+    int cur[RPW], end[RPW];
+    int bad = 0;
+    unsigned long long viol = 0ull; // lanes whose entry broke the "consumed set = window prefix" expectation
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + wave * RPW + r;
+        cur[r] = end[r] = 0;
+        if (row < rows) {
+            cur[r] = wave_uniform(rowptr[row]) - wstart;
+            end[r] = wave_uniform(rowptr[row + 1]) - wstart;
+        }
+    }
+    constexpr int NB = 4, AHEAD = 3;
+    static_assert(RPW == NB, "one window buffer per row of the wave");
+    double wdb[NB];
+    dma_tile(t_lo, 0);
+#pragma unroll
+    for (int r = 0; r < AHEAD; ++r) window_issue5(win_addr(cur[r]), wdb[r]);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); // the first tile has landed (the three windows may be in flight)
+    __syncthreads(); // P
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int cb = (t - t_lo) & 1;
+        dma_tile(t + 1, cb ^ 1); // that buffer was last read before the previous barrier; past t_hi: a tile nobody reads
+        const int tile_lo = t * W2_ROWS;
+        const unsigned tile_base = (unsigned)(uintptr_t)(smem + cb * W2_TILE);
+        const unsigned lb = tile_base + (unsigned)(lane & 15) * 16u;
+        const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+        auto visit = [&](auto rc_) {
+            constexpr int r = decltype(rc_)::value;
+            constexpr int rn = (r + AHEAD) % RPW;
+            window_issue5(win_addr(cur[rn]), wdb[rn]);
+            // operations younger than this row's window: the windows of the two visits in between, this tile's four
+            // DMA operations unless they are older (last visit of the tile), and the window just issued
+            window_wait5<(r == RPW - 1) ? 3 : 7>(wdb[r]);
+            double &q0 = acc[r][0], &q1 = acc[r][1], &q2 = acc[r][2], &q3 = acc[r][3];
+            static_assert(W2_ROWS == 128, "window_select compares against a 128-row tile");
+            int cnt = min(WIN, end[r] - cur[r]);
+            double wd = wdb[r];
+            for (;;) { // see the fourth generation for the structure of this loop
+                unsigned co;
+                double gv;
+                unsigned long long m;
+                window_select5(wd, tile_lo, cnt, eidx, zero_rel, co, gv, m);
+                if (!no_math) { SBLAS_QSTEP4M(0, 1, 2, 3, 8, 9, 10, 11); }
+                const int take = mask_count(m);
+                viol |= m ^ (__builtin_amdgcn_ballot_w64(eidx < take) & W5_VAL_LANES);
+                const bool more = take > 16 || (take >= cnt && cur[r] + take < end[r]);
+                if (__builtin_expect(!more, 1)) {
+                    cur[r] += take;
+                    break;
+                }
+                if (take > 16) {
+                    cur[r] += 16;
+                    cnt -= 16;
+                    // entries 16.. move to 0..: four lanes down, in the value half and in the col_idx half of every DPP row
+                    int lo = __double2loint(wd), hi = __double2hiint(wd);
+                    asm volatile("s_nop 1\n\t"
+                                 "v_mov_b32_dpp %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                                 "v_mov_b32_dpp %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                                 : "+v"(lo), "+v"(hi));
+                    wd = __hiloint2double(hi, lo);
+                } else {
+                    cur[r] += take;
+                    cnt = min(WIN, end[r] - cur[r]);
+                    window_issue5(win_addr(cur[r]), wd);
+                    window_wait5<0>(wd); // drains the queue: the counted waits that follow stay correct (no-ops)
+                }
+            }
+        };
+        visit(std::integral_constant<int, 0>{});
+        visit(std::integral_constant<int, 1>{});
+        visit(std::integral_constant<int, 2>{});
+        visit(std::integral_constant<int, 3>{});
+        if (!no_bar) __syncthreads(); // E_t
+    }
+    window_wait5<0>(wdb[0]); // retire the last (unused) window and tile fetches
+    if (viol != 0ull) bad = 1;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+        if (cur[r] < end[r]) bad = 1; // unconsumed nonzeros
+    if (ABL && ablate != 0) bad = 0;
+    if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+    __syncthreads(); // V
+    const bool fell_back = sm_i[0] != 0;
+    if (fell_back) {
+        // recompute straight from L2, one column per lane, and store in the quad accumulator layout's slot 0
+        const unsigned lane_off = (unsigned)(col0 + lane);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = row0 + wave * RPW + r;
+            int a = 0, b = 0;
+            if (row < rows) {
+                a = wave_uniform(rowptr[row]);
+                b = wave_uniform(rowptr[row + 1]);
+            }
+            acc[r][0] = row_direct(colidx, val, Bt, ld32, lane_off, lane, a, b);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double x = acc[r][j];
+                x += __shfl_xor(x, 16, WAVE);
+                x += __shfl_xor(x, 32, WAVE);
+                acc[r][j] = x;
+            }
+    }
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
+
+    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows
+    double *ctile = smem;
+    if (fell_back) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) ctile[lane * (R + 1) + wave * RPW + r] = acc[r][0];
+    } else if (lane < 16) {
+        const int jj = lane;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int rr = wave * RPW + r;
+            ctile[(2 * jj) * (R + 1) + rr] = acc[r][0];
+            ctile[(2 * jj + 1) * (R + 1) + rr] = acc[r][1];
+            ctile[(32 + 2 * jj) * (R + 1) + rr] = acc[r][2];
+            ctile[(33 + 2 * jj) * (R + 1) + rr] = acc[r][3];
         }
     }
     __syncthreads(); // F
@@ -1941,15 +2322,19 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             if (variant != SPMM_VARIANT_DIRECT_DPP) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
-                const bool gen4 = (variant == SPMM_VARIANT_WINDOW4 || variant == SPMM_VARIANT_AUTO);
-                info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : W3_PANEL;
+                const bool gen4 = (variant == SPMM_VARIANT_WINDOW4);
+                const bool gen5 = (variant == SPMM_VARIANT_WINDOW5 || variant == SPMM_VARIANT_AUTO);
+                info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : gen5 ? W5_PANEL : W3_PANEL;
                 int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
                 const int np = (rows + info_rows - 1) / info_rows;
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
-                                   np, info_rows, rowptr, colidx, gen4 ? 0x7fffffff : ch * 64, 1.0f, winfo);
+                                   np, info_rows, rowptr, colidx, (gen4 || gen5) ? 0x7fffffff : ch * 64,
+                                   /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
+                                      direct kernel, so ask for 8 per row and 128-column tile on average */
+                                   (gen4 || gen5) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0);
                 dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
                 const char *ab = getenv("SBLAS_ABLATE"); /* diagnostics only: wrong results when set */
                 const int ablate = ab ? atoi(ab) : 0;
@@ -1961,11 +2346,30 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
-                if (gen4) {
-                    (void)hipFuncSetAttribute((const void *)spmm_window4_kernel,
+                if (gen5) {
+                    if (ablate != 0) {
+                        (void)hipFuncSetAttribute((const void *)spmm_window5_kernel<true>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
+                        hipLaunchKernelGGL(spmm_window5_kernel<true>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols,
+                                           np, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, ablate,
+                                           (int)nnz);
+                    } else {
+                        (void)hipFuncSetAttribute((const void *)spmm_window5_kernel<false>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
+                        hipLaunchKernelGGL(spmm_window5_kernel<false>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols,
+                                           np, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, 0,
+                                           (int)nnz);
+                    }
+                } else if (gen4 && ablate != 0) {
+                    (void)hipFuncSetAttribute((const void *)spmm_window4_kernel<true>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
-                    hipLaunchKernelGGL(spmm_window4_kernel, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                       colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, ablate, (int)nnz);
+                    hipLaunchKernelGGL(spmm_window4_kernel<true>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np,
+                                       rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, ablate, (int)nnz);
+                } else if (gen4) {
+                    (void)hipFuncSetAttribute((const void *)spmm_window4_kernel<false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
+                    hipLaunchKernelGGL(spmm_window4_kernel<false>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np,
+                                       rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, 0, (int)nnz);
                 } else if (gen2) {
                     if (ch == 1) SBLAS_W_LAUNCH(spmm_window2_kernel, 1);
                     else if (ch == 2) SBLAS_W_LAUNCH(spmm_window2_kernel, 2);
