@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "s-blas_amd", "python"))
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 # stage-2 kernel launched for a 64-column block under each SBLAS_SPMM_VARIANT (s-blas_amd/csrc/kernels.hip)
-KERNEL_OF_VARIANT = {"": "spmm_window5_kernel<false>", "auto": "spmm_window5_kernel<false>", "win5": "spmm_window5_kernel<false>", "win3": "spmm_window3_kernel<7>",
+KERNEL_OF_VARIANT = {"": "spmm_window6_kernel", "auto": "spmm_window6_kernel", "win6": "spmm_window6_kernel", "win5": "spmm_window5_kernel<false>", "win3": "spmm_window3_kernel<7>",
                      "win2": "spmm_window2_kernel<7>", "win4": "spmm_window4_kernel<false>",
                      "dpp": "spmm_direct_dpp_kernel<true>", "direct": "spmm_rowpanel_kernel",
                      "win32": "spmm_window_kernel<2,64,8>", "win64": "spmm_window_kernel<4,128,4>",

@@ -41,6 +41,7 @@ inline int spmm_variant()
     if (!strcmp(e, "win3")) return sblas::SPMM_VARIANT_WINDOW3;
     if (!strcmp(e, "win4")) return sblas::SPMM_VARIANT_WINDOW4;
     if (!strcmp(e, "win5")) return sblas::SPMM_VARIANT_WINDOW5;
+    if (!strcmp(e, "win6")) return sblas::SPMM_VARIANT_WINDOW6;
     if (!strcmp(e, "win32")) return sblas::SPMM_VARIANT_WINDOW_R32;
     if (!strcmp(e, "win64")) return sblas::SPMM_VARIANT_WINDOW_R64;
     if (!strcmp(e, "win128")) return sblas::SPMM_VARIANT_WINDOW_R128;

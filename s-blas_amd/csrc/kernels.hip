@@ -560,17 +560,20 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= npanels) return;
-    const int row = p * panel_rows + lane;
-    int first = 0x7fffffff, last = -1, len = 0;
-    if (lane < panel_rows && row < rows) {
-        const int a = rowptr[row], b = rowptr[row + 1];
-        len = b - a;
-        if (len > 0) {
-            first = colidx[a];
-            last = colidx[b - 1];
+    int first = 0x7fffffff, last = -1, len = 0, mlen = 0;
+    for (int rr = lane; rr < panel_rows; rr += WAVE) { // panels of up to 128 rows: two rows per lane
+        const int row = p * panel_rows + rr;
+        if (row < rows) {
+            const int a = rowptr[row], b = rowptr[row + 1];
+            len += b - a;
+            mlen = max(mlen, b - a);
+            if (b > a) {
+                first = min(first, colidx[a]);
+                last = max(last, colidx[b - 1]);
+            }
         }
     }
-    int nnz = len, mlen = len;
+    int nnz = len;
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
         first = min(first, __shfl_xor(first, m, WAVE));
@@ -1881,6 +1884,268 @@ __global__ __launch_bounds__(1024) void spmm_window5_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2, windowed form, sixth generation: one DPP row per MATRIX row.
+//
+// tools/visit_bench.hip (the visit skeleton of generations 4/5 on L2-resident data) shows two saturated units: the
+// LDS read port (8 KB per sixteen slots = 32 cycles at 256 B/clk -- irreducible, 512 bytes of B per nonzero) and the
+// vector-memory address unit (~15 cycles per wave instruction whatever it fetches: two window loads per visit plus
+// one 1 KB tile-DMA instruction per visit).  This generation cuts the second: a "super-visit" handles FOUR matrix rows
+// at once -- DPP row q of the wave is matrix row 4g+q, lane k of that row holds entries cursor_q + k (set A) and
+// cursor_q + 16 + k (set B) of that row's window, step k broadcasts entry k of all four rows -- so
+//   * four buffer loads fetch 32-entry windows of four rows (8 rows' worth of the old loads), issued right after
+//     the super-visit into the registers it just finished with (no ring), a whole tile ahead of their use;
+//   * a lane accumulates 4 columns of ONE matrix row: 8 accumulator registers per four rows instead of 32, which
+//     pays for G = 2 groups per wave -> 128-row panels, half the tile DMA per nonzero (and no cross-row fold at the end);
+//   * cursors, row ends, counts and the order check live in vector registers (one value per DPP row); the scalar
+//     unit only sees the largest count of the four rows, which sets the number of 4-step blocks to run.
+// The instruction mix of a step is unchanged (v_add_u32_dpp, two ds_read_b128, four v_fmac_f64_dpp).
+// ---------------------------------------------------------------------------------------------
+constexpr int W6_G = 2;                  // groups of four rows per wave
+constexpr int W6_RPW = 4 * W6_G;         // rows per wave
+constexpr int W6_PANEL_MAX = 16 * W6_RPW; // rows per panel when all 16 waves consume (the launcher may use fewer)
+
+// tile membership for one 16-entry half of the four windows; all per-lane (k = lane & 15 is the entry number inside
+// the half, `rem` the entries left in the lane's matrix row counted from this half's first entry)
+__device__ __forceinline__ void window_select6(int wc, double wv, int tile_lo, int rem, int k, unsigned zero_rel,
+                                               unsigned &co, double &gv, unsigned long long &m)
+{
+    int glo, ghi;
+    asm volatile("v_subrev_u32 %[co], %[tlo], %[wc]\n\t"
+                 "v_cmp_gt_i32 %[m], %[rem], %[k]\n\t"
+                 "v_cmp_gt_u32 vcc, 0x80, %[co]\n\t"
+                 "v_lshlrev_b32 %[co], 9, %[co]\n\t"
+                 "s_and_b64 vcc, vcc, %[m]\n\t"
+                 "s_mov_b64 %[m], vcc\n\t"
+                 "v_cndmask_b32 %[co], %[zr], %[co], vcc\n\t"
+                 "v_cndmask_b32 %[glo], 0, %[vlo], vcc\n\t"
+                 "v_cndmask_b32 %[ghi], 0, %[vhi], vcc"
+                 : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
+                 : [tlo] "s"(tile_lo), [wc] "v"(wc), [rem] "v"(rem), [k] "v"(k), [zr] "v"(zero_rel),
+                   [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv))
+                 : "vcc", "scc");
+    gv = __hiloint2double(ghi, glo);
+}
+// the four 32-entry windows of a group: col_idx and val, entries 0-15 (A) and 16-31 (B) of every row
+__device__ __forceinline__ void window_issue6(sblas_rsrc_t rc, sblas_rsrc_t rv, int idx, int &ca, double &va, int &cb,
+                                              double &vb)
+{
+    const int idx2 = idx + 16;
+    asm volatile("buffer_load_dword %0, %4, %6, 0 idxen\n\t"
+                 "buffer_load_dwordx2 %1, %4, %7, 0 idxen\n\t"
+                 "buffer_load_dword %2, %5, %6, 0 idxen\n\t"
+                 "buffer_load_dwordx2 %3, %5, %7, 0 idxen"
+                 : "=&v"(ca), "=&v"(va), "=&v"(cb), "=&v"(vb)
+                 : "v"(idx), "v"(idx2), "s"(rc), "s"(rv)
+                 : "memory");
+}
+template <int NEWER> __device__ __forceinline__ void window_wait6(int &ca, double &va, int &cb, double &vb)
+{
+    static_assert(NEWER == 0 || NEWER == 8, "counts of the sixth-generation tile loop");
+    if (NEWER == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
+}
+
+__global__ __launch_bounds__(1024) void spmm_window6_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int panel_rows, int nnz)
+{
+    constexpr int G = W6_G, RW = W6_RPW, RMAX = W6_PANEL_MAX;
+    static_assert(G == 2, "the vmcnt counts below assume two groups per wave");
+    static_assert(64 * (RMAX + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *zero_row = smem + 2 * W2_TILE;
+    int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    const int2 span = info[panel];
+    if (span.x > span.y) return; // the direct kernel owns this panel
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * panel_rows;
+    const int col0 = blockIdx.y * 64;
+    const unsigned ld32 = (unsigned)ldbt;
+    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const bool active = wave * RW < panel_rows; // this wave has rows (every wave takes part in the tile DMA)
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    double acc[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0;
+
+    // ---- tile DMA (as in the fifth generation): wave w moves Bt rows 8w..8w+7 of a tile
+    const unsigned ldb8 = ld32 * 8u;
+    const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
+    const unsigned pair_off = (unsigned)(lane >> 5) * ldb8 + piece_off;
+    const char *bt_bytes = reinterpret_cast<const char *>(Bt);
+    auto dma_tile = [&](int t, int buf) {
+        const int r0 = t * W2_ROWS + wave * 8;
+        const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)wave * 4096u;
+        if (r0 + 7 <= cols) {
+            const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned brow = (unsigned)min(r0 + 2 * i + (lane >> 5), cols);
+                dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off));
+            }
+        }
+    };
+
+    const int k = lane & 15, q = lane >> 4;
+    // per-lane row state, relative to the first nonzero of the wave's rows (base of the two descriptors)
+    const int wrow = min(row0 + wave * RW, rows);
+    const int wstart = wave_uniform(rowptr[wrow]);
+    const sblas_rsrc_t rc = make_rsrc(colidx + wstart, 4u, (unsigned)(nnz - wstart));
+    const sblas_rsrc_t rv = make_rsrc(val + wstart, 8u, (unsigned)(nnz - wstart));
+    int cur[G], end[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int rr = wave * RW + 4 * g + q; // row inside the panel
+        const int row = row0 + rr;
+        cur[g] = end[g] = 0;
+        if (rr < panel_rows && row < rows) {
+            cur[g] = rowptr[row] - wstart;
+            end[g] = rowptr[row + 1] - wstart;
+        }
+    }
+    unsigned long long viol = 0ull; // lanes whose entry broke the "entries of a tile = window prefix" expectation
+    int wca[G], wcb[G];
+    double wva[G], wvb[G];
+    dma_tile(t_lo, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // the first tile has landed (the windows may be in flight)
+    __syncthreads(); // P
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int cbuf = (t - t_lo) & 1;
+        dma_tile(t + 1, cbuf ^ 1); // that buffer was last read before the previous barrier; past t_hi: a tile nobody reads
+        const int tile_lo = t * W2_ROWS;
+        const unsigned tile_base = (unsigned)(uintptr_t)(smem + cbuf * W2_TILE);
+        const unsigned lb = tile_base + (unsigned)k * 16u;
+        const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+        auto visit = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            // younger than this group's windows: the other group's windows (4) and this tile's DMA (4)
+            window_wait6<8>(wca[g], wva[g], wcb[g], wvb[g]);
+            double &q0 = acc[g][0], &q1 = acc[g][1], &q2 = acc[g][2], &q3 = acc[g][3];
+            for (;;) {
+                const int rem = end[g] - cur[g];
+                unsigned coA, coB;
+                double gvA, gvB;
+                unsigned long long mA, mB;
+                window_select6(wca[g], wva[g], tile_lo, rem, k, zero_rel, coA, gvA, mA);
+                window_select6(wcb[g], wvb[g], tile_lo, rem - 16, k, zero_rel, coB, gvB, mB);
+                // entries of this tile per matrix row (= per DPP row), as a per-lane value
+                const unsigned fa = q < 2 ? (unsigned)mA : (unsigned)(mA >> 32);
+                const unsigned fb = q < 2 ? (unsigned)mB : (unsigned)(mB >> 32);
+                const int sh = (q & 1) * 16;
+                const int take = __popc((fa >> sh) & 0xffffu) + __popc((fb >> sh) & 0xffffu);
+                // with ascending columns they are exactly the first `take` entries of the row's window
+                viol |= mA ^ __builtin_amdgcn_ballot_w64(k < take);
+                viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
+                int mx = max(max(__builtin_amdgcn_readlane(take, 0), __builtin_amdgcn_readlane(take, 16)),
+                             max(__builtin_amdgcn_readlane(take, 32), __builtin_amdgcn_readlane(take, 48)));
+                {
+                    const unsigned co = coA;
+                    const double gv = gvA;
+                    if (mx > 0) { SBLAS_QSTEP4(0, 1, 2, 3); }
+                    if (mx > 4) { SBLAS_QSTEP4(4, 5, 6, 7); }
+                    if (mx > 8) { SBLAS_QSTEP4(8, 9, 10, 11); }
+                    if (mx > 12) { SBLAS_QSTEP4(12, 13, 14, 15); }
+                }
+                if (mx > 16) {
+                    const unsigned co = coB;
+                    const double gv = gvB;
+                    SBLAS_QSTEP4(0, 1, 2, 3);
+                    if (mx > 20) { SBLAS_QSTEP4(4, 5, 6, 7); }
+                    if (mx > 24) { SBLAS_QSTEP4(8, 9, 10, 11); }
+                    if (mx > 28) { SBLAS_QSTEP4(12, 13, 14, 15); }
+                }
+                cur[g] += take;
+                // a row that used its whole window and has more: fetch the next windows now and go again (rare:
+                // more than 32 nonzeros of a row inside one 128-column tile)
+                const bool more = take >= 32 && cur[g] < end[g];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(more) == 0ull, 1)) break;
+                window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+                window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]); // drains the queue: later counted waits stay correct
+            }
+            // next tile's windows, into the registers this super-visit is done with
+            window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+        };
+        if (active) {
+            visit(std::integral_constant<int, 0>{});
+            visit(std::integral_constant<int, 1>{});
+        }
+        // the DMA of this tile is older than the eight window loads just issued
+        if (active) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // E_t
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wca[0]), "+v"(wca[1])::"memory"); // retire the unused last fetches
+    int bad = viol != 0ull ? 1 : 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (__builtin_amdgcn_ballot_w64(cur[g] < end[g]) != 0ull) bad = 1; // unconsumed nonzeros
+    if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+    __syncthreads(); // V
+    const bool fell_back = sm_i[0] != 0;
+    if (fell_back) {
+        // recompute straight from L2, one column per lane: acc[g][j] <- row 4g+j of the wave
+        const unsigned lane_off = (unsigned)(col0 + lane);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = wave * RW + 4 * g + j;
+                const int row = row0 + rr;
+                int a = 0, b = 0;
+                if (rr < panel_rows && row < rows) {
+                    a = wave_uniform(rowptr[row]);
+                    b = wave_uniform(rowptr[row + 1]);
+                }
+                acc[g][j] = row_direct(colidx, val, Bt, ld32, lane_off, lane, a, b);
+            }
+    }
+    if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
+
+    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows
+    double *ctile = smem;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (fell_back) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ctile[lane * (RMAX + 1) + wave * RW + 4 * g + j] = acc[g][j];
+        } else {
+            const int rr = wave * RW + 4 * g + q;
+            ctile[(2 * k) * (RMAX + 1) + rr] = acc[g][0];
+            ctile[(2 * k + 1) * (RMAX + 1) + rr] = acc[g][1];
+            ctile[(32 + 2 * k) * (RMAX + 1) + rr] = acc[g][2];
+            ctile[(33 + 2 * k) * (RMAX + 1) + rr] = acc[g][3];
+        }
+    }
+    __syncthreads(); // F
+    const int nrows = min(panel_rows, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = tid; idx < 64 * panel_rows; idx += 1024) {
+        const int r = idx % panel_rows, j = idx / panel_rows;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (RMAX + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 2, direct form with DPP broadcast (any matrix; no assumption on column order or locality).
 //
 // A wave owns a row and a 128-column tile of C: every lane holds TWO adjacent columns, so a Bt row segment
@@ -2316,25 +2581,49 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
         if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO || variant == SPMM_VARIANT_WINDOW2 ||
-            variant == SPMM_VARIANT_WINDOW3 || variant == SPMM_VARIANT_WINDOW4) {
+            variant == SPMM_VARIANT_WINDOW3 || variant == SPMM_VARIANT_WINDOW4 || variant == SPMM_VARIANT_WINDOW5 ||
+            variant == SPMM_VARIANT_WINDOW6) {
             const int2 *info = nullptr;
             int info_rows = 1;
             if (variant != SPMM_VARIANT_DIRECT_DPP) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
                 const bool gen4 = (variant == SPMM_VARIANT_WINDOW4);
-                const bool gen5 = (variant == SPMM_VARIANT_WINDOW5 || variant == SPMM_VARIANT_AUTO);
+                const bool gen5 = (variant == SPMM_VARIANT_WINDOW5);
+                const bool gen6 = (variant == SPMM_VARIANT_WINDOW6 || variant == SPMM_VARIANT_AUTO);
                 info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : gen5 ? W5_PANEL : W3_PANEL;
+                if (gen6) {
+                    // one workgroup per CU at a time and every panel costs about the same: pick the panel height
+                    // (a multiple of the 8 rows of a wave) that minimises rounds x height
+                    int ncu = 256;
+                    int dev = 0;
+                    if (hipGetDevice(&dev) == hipSuccess)
+                        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                    if (ncu < 1) ncu = 1;
+                    const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments */
+                    int best = W6_PANEL_MAX;
+                    long best_cost = -1;
+                    for (int r = W6_PANEL_MAX; r >= 4 * W6_RPW; r -= W6_RPW) {
+                        const long panels = (rows + r - 1) / r;
+                        const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 8); // + fixed cost per panel
+                        if (best_cost < 0 || cost < best_cost) {
+                            best_cost = cost;
+                            best = r;
+                        }
+                    }
+                    info_rows = best;
+                    if (pr && atoi(pr) >= W6_RPW && atoi(pr) <= W6_PANEL_MAX && atoi(pr) % W6_RPW == 0) info_rows = atoi(pr);
+                }
                 int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
                 const int np = (rows + info_rows - 1) / info_rows;
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
-                                   np, info_rows, rowptr, colidx, (gen4 || gen5) ? 0x7fffffff : ch * 64,
+                                   np, info_rows, rowptr, colidx, (gen4 || gen5 || gen6) ? 0x7fffffff : ch * 64,
                                    /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
                                       direct kernel, so ask for 8 per row and 128-column tile on average */
-                                   (gen4 || gen5) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0);
+                                   (gen4 || gen5 || gen6) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0);
                 dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
                 const char *ab = getenv("SBLAS_ABLATE"); /* diagnostics only: wrong results when set */
                 const int ablate = ab ? atoi(ab) : 0;
@@ -2346,7 +2635,12 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
-                if (gen5) {
+                if (gen6) {
+                    (void)hipFuncSetAttribute((const void *)spmm_window6_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
+                    hipLaunchKernelGGL(spmm_window6_kernel, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
+                                       colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, info_rows, (int)nnz);
+                } else if (gen5) {
                     if (ablate != 0) {
                         (void)hipFuncSetAttribute((const void *)spmm_window5_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
