@@ -48,9 +48,10 @@ def measured_traffic(kernel, rows, nnz, n):
             w = d.get("workload", {})
             if (w.get("rows"), w.get("nnz"), w.get("n")) != (rows, nnz, n):
                 continue
-            k = d["kernels"].get("sblas::" + kernel)
-            if k:
-                return k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+            # (template arguments chosen inside the library, e.g. the groups per wave, are part of the profiled name)
+            hits = [v for name, v in d["kernels"].items() if name == "sblas::" + kernel or name.startswith("sblas::" + kernel + "<")]
+            if hits:
+                return hits[0]["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None

@@ -1900,9 +1900,8 @@ __global__ __launch_bounds__(1024) void spmm_window5_kernel(
 //     unit only sees the largest count of the four rows, which sets the number of 4-step blocks to run.
 // The instruction mix of a step is unchanged (v_add_u32_dpp, two ds_read_b128, four v_fmac_f64_dpp).
 // ---------------------------------------------------------------------------------------------
-constexpr int W6_G = 2;                  // groups of four rows per wave
-constexpr int W6_RPW = 4 * W6_G;         // rows per wave
-constexpr int W6_PANEL_MAX = 16 * W6_RPW; // rows per panel when all 16 waves consume (the launcher may use fewer)
+constexpr int W6_GMAX = 3;                   // groups of four rows per wave: 2 or 3 (template parameter)
+
 
 // tile membership for one 16-entry half of the four windows; all per-lane (k = lane & 15 is the entry number inside
 // the half, `rem` the entries left in the lane's matrix row counted from this half's first entry)
@@ -1930,6 +1929,8 @@ __device__ __forceinline__ void window_issue6(sblas_rsrc_t rc, sblas_rsrc_t rv, 
                                               double &vb)
 {
     const int idx2 = idx + 16;
+    // (non-temporal loads here cost 19 %: every entry is used by two or three consecutive windows and those re-reads
+    //  must hit)
     asm volatile("buffer_load_dword %0, %4, %6, 0 idxen\n\t"
                  "buffer_load_dwordx2 %1, %4, %7, 0 idxen\n\t"
                  "buffer_load_dword %2, %5, %6, 0 idxen\n\t"
@@ -1940,18 +1941,30 @@ __device__ __forceinline__ void window_issue6(sblas_rsrc_t rc, sblas_rsrc_t rv, 
 }
 template <int NEWER> __device__ __forceinline__ void window_wait6(int &ca, double &va, int &cb, double &vb)
 {
-    static_assert(NEWER == 0 || NEWER == 8, "counts of the sixth-generation tile loop");
-    if (NEWER == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
+    static_assert(NEWER == 0 || NEWER == 4 || NEWER == 8, "counts of the sixth-generation tile loop");
+    if (NEWER == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
+    else if (NEWER == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ca), "+v"(va), "+v"(cb), "+v"(vb)::"memory");
 }
+template <int N> __device__ __forceinline__ void vm_wait6()
+{
+    static_assert(N == 8 || N == 12, "counts of the sixth-generation tile loop");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
+// ABL: diagnostic switches compiled in (SBLAS_ABLATE: 0x10000 no LDS reads / FMAs, 0x20000 no tile DMA, 0x40000 no
+// per-tile barrier; wrong results)
+template <int G, bool ABL>
 __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int panel_rows, int nnz)
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int panel_rows, int nnz, int ablate)
 {
-    constexpr int G = W6_G, RW = W6_RPW, RMAX = W6_PANEL_MAX;
-    static_assert(G == 2, "the vmcnt counts below assume two groups per wave");
+    const bool no_math = ABL && (ablate & 0x10000) != 0, no_dma = ABL && (ablate & 0x20000) != 0;
+    const bool no_bar = ABL && (ablate & 0x40000) != 0;
+    constexpr int RW = 4 * G, RMAX = 16 * RW;
+    static_assert(G == 2 || G == 3, "two or three groups per wave (the counted vmcnt waits are 4 G)");
     static_assert(64 * (RMAX + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *zero_row = smem + 2 * W2_TILE;
@@ -1968,7 +1981,10 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     const int col0 = blockIdx.y * 64;
     const unsigned ld32 = (unsigned)ldbt;
     const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
-    const bool active = wave * RW < panel_rows; // this wave has rows (every wave takes part in the tile DMA)
+    // waves 12-15 load the tiles, waves 0-11 consume (a wave that did both had its window loads retire behind its own
+    // tile fetches -- vmcnt is in order -- and the kernel ran twice as long)
+    const bool loader = wave >= 12;
+    const bool active = !loader && wave * RW < panel_rows; // this wave has rows
 
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
@@ -1984,16 +2000,22 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
     const unsigned pair_off = (unsigned)(lane >> 5) * ldb8 + piece_off;
     const char *bt_bytes = reinterpret_cast<const char *>(Bt);
-    auto dma_tile = [&](int t, int buf) {
-        const int r0 = t * W2_ROWS + wave * 8;
-        const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)wave * 4096u;
-        if (r0 + 7 <= cols) {
+    int dummy = 0;
+    // instructions i0 .. i1-1 of the wave's share (four in all); issued in two or three instalments per tile: with all
+    // four at the top of a tile the kernel ran twice as long (SBLAS_ABLATE experiments: half the volume cost nothing,
+    // the full volume 150 us whatever the source or the destination)
+    auto dma_part = [&](int t, int buf, int i0, int i1) {
+        const int lw = wave - 12;
+        const int r0 = t * W2_ROWS + lw * 32;
+        const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)lw * 16384u;
+        if (no_dma) {
+            // (read-write operand: the landing register must stay reserved while the loads are in flight)
+            for (int i = i0; i < i1; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(bt_bytes) : "memory");
+        } else if (r0 + 31 <= cols) {
             const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
+            for (int i = i0; i < i1; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
         } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 const unsigned brow = (unsigned)min(r0 + 2 * i + (lane >> 5), cols);
                 dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off));
             }
@@ -2020,22 +2042,25 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     unsigned long long viol = 0ull; // lanes whose entry broke the "entries of a tile = window prefix" expectation
     int wca[G], wcb[G];
     double wva[G], wvb[G];
-    dma_tile(t_lo, 0);
+    if (loader) dma_part(t_lo, 0, 0, 16);
 #pragma unroll
     for (int g = 0; g < G; ++g) window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // the first tile has landed (the windows may be in flight)
+    // everything lands before the loop starts, so its counted waits (written for the steady state) hold from the
+    // first tile on
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads(); // P
     for (int t = t_lo; t <= t_hi; ++t) {
         const int cbuf = (t - t_lo) & 1;
-        dma_tile(t + 1, cbuf ^ 1); // that buffer was last read before the previous barrier; past t_hi: a tile nobody reads
+        // next tile (that buffer was last read before the previous barrier)
+        if (loader && t < t_hi) dma_part(t + 1, cbuf ^ 1, 0, 16);
         const int tile_lo = t * W2_ROWS;
         const unsigned tile_base = (unsigned)(uintptr_t)(smem + cbuf * W2_TILE);
         const unsigned lb = tile_base + (unsigned)k * 16u;
         const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
         auto visit = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            // younger than this group's windows: the other group's windows (4) and this tile's DMA (4)
-            window_wait6<8>(wca[g], wva[g], wcb[g], wvb[g]);
+            // younger than this group's windows: the other groups' windows (4 each)
+            window_wait6<4 * (G - 1)>(wca[g], wva[g], wcb[g], wvb[g]);
             double &q0 = acc[g][0], &q1 = acc[g][1], &q2 = acc[g][2], &q3 = acc[g][3];
             for (;;) {
                 const int rem = end[g] - cur[g];
@@ -2054,6 +2079,9 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
                 viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
                 int mx = max(max(__builtin_amdgcn_readlane(take, 0), __builtin_amdgcn_readlane(take, 16)),
                              max(__builtin_amdgcn_readlane(take, 32), __builtin_amdgcn_readlane(take, 48)));
+                if (no_math) mx = 0;
+                // (blocks of eight steps with the second half's LDS reads issued ahead of the first half's FMAs were
+                //  tried: no gain)
                 {
                     const unsigned co = coA;
                     const double gv = gvA;
@@ -2084,17 +2112,18 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
         if (active) {
             visit(std::integral_constant<int, 0>{});
             visit(std::integral_constant<int, 1>{});
+            if constexpr (G > 2) visit(std::integral_constant<int, 2>{});
         }
-        // the DMA of this tile is older than the eight window loads just issued
-        if (active) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // E_t
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory"); // the tile has landed
+        if (!no_bar) __syncthreads(); // E_t
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wca[0]), "+v"(wca[1])::"memory"); // retire the unused last fetches
+#pragma unroll
+    for (int g = 0; g < G; ++g) window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]); // retire the unused last fetches
     int bad = viol != 0ull ? 1 : 0;
 #pragma unroll
     for (int g = 0; g < G; ++g)
         if (__builtin_amdgcn_ballot_w64(cur[g] < end[g]) != 0ull) bad = 1; // unconsumed nonzeros
+    if (ABL && ablate != 0) bad = 0;
     if (bad && lane == 0) atomicOr(&sm_i[0], 1);
     __syncthreads(); // V
     const bool fell_back = sm_i[0] != 0;
@@ -2592,27 +2621,37 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const bool gen5 = (variant == SPMM_VARIANT_WINDOW5);
                 const bool gen6 = (variant == SPMM_VARIANT_WINDOW6 || variant == SPMM_VARIANT_AUTO);
                 info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : gen5 ? W5_PANEL : W3_PANEL;
+                int gen6_g = 2;
                 if (gen6) {
-                    // one workgroup per CU at a time and every panel costs about the same: pick the panel height
-                    // (a multiple of the 8 rows of a wave) that minimises rounds x height
+                    // one workgroup per CU at a time: pick the groups per wave (2 or 3) and the panel height (a
+                    // multiple of the rows of a wave) that minimise rounds x (height + per-tile fixed cost)
                     int ncu = 256;
                     int dev = 0;
                     if (hipGetDevice(&dev) == hipSuccess)
                         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
                     if (ncu < 1) ncu = 1;
-                    const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments */
-                    int best = W6_PANEL_MAX;
+                    int best = 128;
                     long best_cost = -1;
-                    for (int r = W6_PANEL_MAX; r >= 4 * W6_RPW; r -= W6_RPW) {
-                        const long panels = (rows + r - 1) / r;
-                        const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 8); // + fixed cost per panel
-                        if (best_cost < 0 || cost < best_cost) {
-                            best_cost = cost;
-                            best = r;
+                    for (int g = 2; g <= W6_GMAX; ++g)
+                        for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
+                            const long panels = (rows + r - 1) / r;
+                            // measured on the bench matrix: three groups per wave cost ~15 % more per row
+                            const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 40) * (g == 3 ? 23 : 20);
+                            if (best_cost < 0 || cost < best_cost) {
+                                best_cost = cost;
+                                best = r;
+                                gen6_g = g;
+                            }
+                        }
+                    info_rows = best;
+                    const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments: "<rows>" or "<rows>,<groups>" */
+                    if (pr) {
+                        int r = atoi(pr), g = strchr(pr, ',') ? atoi(strchr(pr, ',') + 1) : (r % 12 == 0 && r > 128 ? 3 : 2);
+                        if ((g == 2 || g == 3) && r >= 4 * g && r <= 48 * g && r % (4 * g) == 0) {
+                            info_rows = r;
+                            gen6_g = g;
                         }
                     }
-                    info_rows = best;
-                    if (pr && atoi(pr) >= W6_RPW && atoi(pr) <= W6_PANEL_MAX && atoi(pr) % W6_RPW == 0) info_rows = atoi(pr);
                 }
                 int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
                 const int np = (rows + info_rows - 1) / info_rows;
@@ -2636,10 +2675,23 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
                 if (gen6) {
-                    (void)hipFuncSetAttribute((const void *)spmm_window6_kernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2_LDS_BYTES);
-                    hipLaunchKernelGGL(spmm_window6_kernel, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                       colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, info_rows, (int)nnz);
+#define SBLAS_W6_LAUNCH(GV, ABLV, ABLARG)                                                                             \
+    do {                                                                                                             \
+        const size_t lds_bytes = W2_LDS_BYTES + (ABLV ? 20480 : 0); /* diagnostics: scratch area for the DMA */        \
+        (void)hipFuncSetAttribute((const void *)spmm_window6_kernel<GV, ABLV>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                       \
+        hipLaunchKernelGGL((spmm_window6_kernel<GV, ABLV>), wgrid, dim3(1024), lds_bytes, s, rows, cols, np,         \
+                           rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, info_rows, (int)nnz,        \
+                           ABLARG);                                                                                  \
+    } while (0)
+                    if (ablate != 0) {
+                        if (gen6_g == 3) SBLAS_W6_LAUNCH(3, true, ablate);
+                        else SBLAS_W6_LAUNCH(2, true, ablate);
+                    } else {
+                        if (gen6_g == 3) SBLAS_W6_LAUNCH(3, false, 0);
+                        else SBLAS_W6_LAUNCH(2, false, 0);
+                    }
+#undef SBLAS_W6_LAUNCH
                 } else if (gen5) {
                     if (ablate != 0) {
                         (void)hipFuncSetAttribute((const void *)spmm_window5_kernel<true>,

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries written by tools/profile.sh (gpurun_out/prof) into profiles/ (tracked) and merge the
+FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_hbm_traffic.json, the file bench.py reads `roofline.traffic`
+from.  Usage: python tools/collect_profiles.py [round-prefix, default r01]"""
+import collections, csv, glob, json, os, shutil, sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = "gpurun_out/prof", "profiles"
+os.makedirs(dst, exist_ok=True)
+for op in ("spmm", "spmv"):
+    f = glob.glob(f"{src}/{op}/*/*kernel_stats.csv")
+    if f:
+        shutil.copy(f[0], f"{dst}/{rnd}_{op}_bench_kernel_stats.csv")
+        for row in csv.DictReader(open(f[0])):
+            print(op, row["Name"][:60], row["Calls"], "avg ns", row["AverageNs"])
+for name in ("bench_default", "bench_spmv"):
+    if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
+        shutil.copy(f"{src}/{name}.json", f"{dst}/{rnd}_{name}.json")
+
+CORR = ("gfx950: FETCH_SIZE counts 64 B per 128 B request -> read bytes = 2*FETCH_SIZE (MI355X_MICROARCH.md, HBM); "
+        "WRITE_SIZE exact; unit KiB")
+per = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{src}/pmc_{c}/*/*counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == c:
+                agg[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+        for k, v in agg.items():
+            per[k][c] = sum(v) / len(v)
+path = f"{dst}/{rnd}_hbm_traffic.json"
+doc = json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
+doc["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 "
+                  "--warmup 1 --cpu-seconds 0")
+for k, v in per.items():
+    if "sblas::" not in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    doc["kernels"][k] = {"FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
+                         "hbm_bytes_per_launch_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
+                         "correction": CORR}
+    print("traffic", k, doc["kernels"][k]["hbm_bytes_per_launch_corrected"])
+json.dump(doc, open(path, "w"), indent=1)
