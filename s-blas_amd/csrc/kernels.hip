@@ -2372,7 +2372,7 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
 // L2), then the partial sums are folded with xor-shuffles inside the wave -- the wave64 successor of
 // the reference's unused sum_32_shfl (utility.h:241-246).
 // ---------------------------------------------------------------------------------------------
-template <int LPR>
+template <int LPR, bool GATHER = true> // GATHER = false: diagnostic build that reads x[lane] (wrong results)
 __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__restrict__ rowptr,
                                                       const int *__restrict__ colidx,
                                                       const double *__restrict__ val,
@@ -2390,8 +2390,8 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
         for (; p + LPR < p1; p += 2 * LPR) {
             const int c0 = colidx[p], c1 = colidx[p + LPR];
             const double a0 = val[p], a1 = val[p + LPR];
-            s0 = fma(a0, x[c0], s0);
-            s1 = fma(a1, x[c1], s1);
+            s0 = fma(a0, x[GATHER ? c0 : (c0 & 63)], s0);
+            s1 = fma(a1, x[GATHER ? c1 : (c1 & 63)], s1);
         }
         if (p < p1) s0 = fma(val[p], x[colidx[p]], s0);
     }
@@ -2400,6 +2400,54 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
     for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, WAVE);
     if (row < rows && l == 0) {
         const double r = alpha * s;
+        y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for long rows, flat form.  The lanes-per-row kernel above walks a 400-nonzero row in four dependent trips of
+// {col/val load -> x gather -> FMA} with at most 1.5 KB in flight per wave.  Here a wave issues the (col, val) loads
+// of S slices of 64 nonzeros back to back, then all gathers, then the FMAs -- two memory round trips per S*64
+// nonzeros -- with NO predication: indices are clamped to the last nonzero of the row and the values of the clamped
+// lanes are zeroed afterwards (the round-1 "burst" kernel predicated every load and hipcc put a full vmcnt(0)
+// between them: slower than the plain kernel).
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void spmv_csr_flat_kernel(int rows, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ x, double alpha, double beta,
+                                                           double *__restrict__ y)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int p0 = wave_uniform(rowptr[row]), p1 = wave_uniform(rowptr[row + 1]);
+    double s0 = 0.0, s1 = 0.0;
+    const int last = p1 - 1;
+    for (int base = p0; base < p1; base += S * WAVE) {
+        int c[S];
+        double a[S], xv[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int p = min(base + u * WAVE + lane, last);
+            c[u] = colidx[p];
+            a[u] = val[p];
+        }
+#pragma unroll
+        for (int u = 0; u < S; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const double av = (base + u * WAVE + lane <= last) ? a[u] : 0.0;
+            if (u & 1) s1 = fma(av, xv[u], s1);
+            else s0 = fma(av, xv[u], s0);
+        }
+    }
+    double sum = s0 + s1;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+    if (lane == 0) {
+        const double r = alpha * sum;
         y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
     }
 }
@@ -2818,6 +2866,21 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     // SBLAS_SPMV_VARIANT=burst|window selects the two experimental long-row kernels (both correct, both slower:
     // 116 us and 83 us vs 82 us) for A/B runs and tests.
     const char *sv = getenv("SBLAS_SPMV_VARIANT");
+    if (avg > 96.0 && sv && (!strcmp(sv, "flat4") || !strcmp(sv, "flat8") || !strcmp(sv, "flat2"))) {
+        const dim3 g((unsigned)((rows + 3) / 4));
+        if (!strcmp(sv, "flat8"))
+            hipLaunchKernelGGL(spmv_csr_flat_kernel<8>, g, dim3(256), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
+        else if (!strcmp(sv, "flat4"))
+            hipLaunchKernelGGL(spmv_csr_flat_kernel<4>, g, dim3(256), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
+        else
+            hipLaunchKernelGGL(spmv_csr_flat_kernel<2>, g, dim3(256), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
+        return hipGetLastError();
+    }
+    if (sv && !strcmp(sv, "nogather")) { // diagnostics only
+        hipLaunchKernelGGL((spmv_csr_kernel<64, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, rowptr,
+                           colidx, val, x, alpha, beta, y);
+        return hipGetLastError();
+    }
     if (avg > 96.0 && sv && !strcmp(sv, "burst")) {
         hipLaunchKernelGGL(spmv_csr_burst_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, rowptr,
                            colidx, val, x, alpha, beta, y);
