@@ -174,7 +174,10 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
                "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
                "config": {"workload": "SpMV y=A*x+y, %s, nnz=%d, replicas only" % (name, nnz), "rows": rows, "nnz": nnz},
-               "roofline": {"bound": "hbm", "kernel": "spmv_csr_kernel", "achieved": round(alg / t_k / 1e9, 1),
+               "roofline": {"bound": "hbm",
+                            "kernel": ("spmv_csr_lds_kernel" if nnz > 96 * rows and os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto", "lds")
+                                       else "spmv_csr_kernel"),
+                            "achieved": round(alg / t_k / 1e9, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4),
                             "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_k * 1e3, 5)},
                "cpu_baseline": None}

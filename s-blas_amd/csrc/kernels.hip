@@ -2405,6 +2405,147 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// SpMV for long rows, x window in LDS (second attempt).  Diagnostics on the plain kernel: the A stream alone runs at
+// 6.8 TB/s with the same row-per-wave shape (tools/stream_bench.hip), replacing the gather by a one-line read still
+// leaves 76 us -- what costs is the second, dependent vector-memory access per slice (address unit ~15 cycles per
+// instruction, more for a 40-line gather).  Here a 16-row block (one row per wave) fetches the x range its rows span
+// into LDS once and gathers from there; the stream loads of a row (up to 448 nonzeros) are issued right after its row
+// pointers, BEFORE the window is known, so the block-wide min/max, the window load and their three barriers hide
+// behind the HBM latency of the stream (the barriers are `s_barrier` without the vmcnt(0) of __syncthreads).
+// Columns outside the window (unsorted rows) are fetched from global memory lane by lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPMV_LDS_ROWS = 16;   // = waves per block
+constexpr int SPMV_LDS_CAP = 5120;  // doubles (40 KiB): two blocks per CU
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RW, int S> // RW rows per wave (16 RW rows per block), S slices of 64 nonzeros fetched ahead per row
+__global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ x, double alpha, double beta,
+                                                           double *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    __shared__ int sm_lo, sm_hi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = (blockIdx.x * SPMV_LDS_ROWS + wave) * RW;
+    if (tid == 0) {
+        sm_lo = 0x7fffffff;
+        sm_hi = -1;
+    }
+    int p0[RW], last[RW];
+    bool has[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int a0 = 0, a1 = 0;
+        if (row0 + r < rows) {
+            a0 = wave_uniform(rowptr[row0 + r]);
+            a1 = wave_uniform(rowptr[row0 + r + 1]);
+        }
+        p0[r] = a0;
+        has[r] = a1 > a0;
+        last[r] = max(a1 - 1, a0);
+    }
+    // the two ends of every row first (lane 2r: first column of row r, lane 2r+1: its last column), then the first
+    // burst of the streams
+    int c[RW][S];
+    double a[RW][S];
+    int ce = 0;
+    bool ce_valid = false;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (has[r] && (lane >> 1) == r) {
+            ce = colidx[(lane & 1) ? last[r] : p0[r]];
+            ce_valid = true;
+        }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (has[r]) {
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+                const int p = min(p0[r] + u * WAVE + lane, last[r]);
+                c[r][u] = colidx[p];
+                a[r][u] = val[p];
+            }
+        }
+    lds_barrier(); // sm_lo / sm_hi initialised
+    if (ce_valid) {
+        if (lane & 1) atomicMax(&sm_hi, ce);
+        else atomicMin(&sm_lo, ce);
+    }
+    lds_barrier();
+    int lo = sm_lo, hi = sm_hi;
+    if (lo > hi) {
+        lo = 0;
+        hi = -1;
+    }
+    lo = max(lo, 0);
+    hi = min(hi, cols - 1);
+    // a span that does not fit is not staged at all: every gather then goes to global memory, as in the plain kernel
+    const int wlen = (hi - lo + 1 <= SPMV_LDS_CAP) ? hi - lo + 1 : 0;
+    if (wlen > 0) {
+        // the whole window in one burst of loads (clamped indices), then the stores
+        constexpr int PASSES = SPMV_LDS_CAP / 1024;
+        double t[PASSES];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) t[j] = x[lo + min(tid + 1024 * j, wlen - 1)];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j)
+            if (tid + 1024 * j < wlen) xs[tid + 1024 * j] = t[j];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        double s0 = 0.0, s1 = 0.0;
+        if (has[r]) {
+            for (int base = p0[r];;) {
+                double xv[S];
+                bool out = false;
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const bool live = base + u * WAVE + lane <= last[r];
+                    const unsigned rel = (unsigned)(c[r][u] - lo);
+                    const bool inw = rel < (unsigned)wlen;
+                    xv[u] = xs[inw ? rel : 0u];
+                    out |= live && !inw;
+                }
+                if (__builtin_amdgcn_ballot_w64(out) != 0ull) { // columns outside the window (unsorted rows, wide spans)
+#pragma unroll
+                    for (int u = 0; u < S; ++u) {
+                        const bool live = base + u * WAVE + lane <= last[r];
+                        if (live && (unsigned)(c[r][u] - lo) >= (unsigned)wlen) xv[u] = x[c[r][u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const double av = (base + u * WAVE + lane <= last[r]) ? a[r][u] : 0.0;
+                    if (u & 1) s1 = fma(av, xv[u], s1);
+                    else s0 = fma(av, xv[u], s0);
+                }
+                base += S * WAVE;
+                if (base > last[r]) break;
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const int p = min(base + u * WAVE + lane, last[r]);
+                    c[r][u] = colidx[p];
+                    a[r][u] = val[p];
+                }
+            }
+        }
+        double sum = s0 + s1;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+        if (lane == 0) {
+            const double res = alpha * sum;
+            y[row] = (beta == 0.0) ? res : fma(beta, y[row], res);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SpMV for long rows, flat form.  The lanes-per-row kernel above walks a 400-nonzero row in four dependent trips of
 // {col/val load -> x gather -> FMA} with at most 1.5 KB in flight per wave.  Here a wave issues the (col, val) loads
 // of S slices of 64 nonzeros back to back, then all gathers, then the FMAs -- two memory round trips per S*64
@@ -2862,9 +3003,8 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
                        const double *val, const double *x, double alpha, double beta, double *y)
 {
     const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
-    // Default: the generic lanes-per-row kernel (fastest measured in round 1: 4.1 TB/s on the bench matrix).
-    // SBLAS_SPMV_VARIANT=burst|window selects the two experimental long-row kernels (both correct, both slower:
-    // 116 us and 83 us vs 82 us) for A/B runs and tests.
+    // Rows up to 96 nonzeros on average: the generic lanes-per-row kernel.  SBLAS_SPMV_VARIANT=burst|window|flat2|
+    // flat4|flat8 select experimental long-row kernels (all correct, all slower) for A/B runs and tests.
     const char *sv = getenv("SBLAS_SPMV_VARIANT");
     if (avg > 96.0 && sv && (!strcmp(sv, "flat4") || !strcmp(sv, "flat8") || !strcmp(sv, "flat2"))) {
         const dim3 g((unsigned)((rows + 3) / 4));
@@ -2876,6 +3016,26 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
             hipLaunchKernelGGL(spmv_csr_flat_kernel<2>, g, dim3(256), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
         return hipGetLastError();
     }
+#define SBLAS_SPMV_LDS(RWV, SV)                                                                                      \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute((const void *)spmv_csr_lds_kernel<RWV, SV>,                                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SPMV_LDS_CAP * sizeof(double))); \
+        hipLaunchKernelGGL((spmv_csr_lds_kernel<RWV, SV>),                                                           \
+                           dim3((unsigned)((rows + SPMV_LDS_ROWS * RWV - 1) / (SPMV_LDS_ROWS * RWV))), dim3(1024),    \
+                           SPMV_LDS_CAP * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha, beta, y);    \
+        return hipGetLastError();                                                                                    \
+    } while (0)
+    // long rows: x window in LDS (bench matrix: 70-73 us vs 82-85 us for the lanes-per-row kernel); a block whose
+    // rows span more than the LDS window degrades to global gathers by itself.  SBLAS_SPMV_VARIANT=plain keeps the
+    // lanes-per-row kernel for A/B runs.
+    if (avg > 96.0 && (!sv || !*sv || !strcmp(sv, "auto"))) {
+        if (avg <= 200.0) SBLAS_SPMV_LDS(1, 4);
+        SBLAS_SPMV_LDS(1, 7);
+    }
+    if (avg > 96.0 && sv && !strcmp(sv, "lds")) SBLAS_SPMV_LDS(1, 7);
+    if (avg > 96.0 && sv && !strcmp(sv, "lds2")) SBLAS_SPMV_LDS(2, 7);
+    if (avg > 96.0 && sv && !strcmp(sv, "lds2s4")) SBLAS_SPMV_LDS(2, 4);
+    if (avg > 96.0 && sv && !strcmp(sv, "lds1s4")) SBLAS_SPMV_LDS(1, 4);
     if (sv && !strcmp(sv, "nogather")) { // diagnostics only
         hipLaunchKernelGGL((spmv_csr_kernel<64, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, rowptr,
                            colidx, val, x, alpha, beta, y);
