@@ -379,6 +379,63 @@ def main():
             "note": "rank-0 stage times; merge = torch.distributed all_reduce (RCCL) on the full M x N buffer as spmm.h:260-262",
         }
 
+        # ---- method 2, fast merge: packed row blocks, all-gather, one scatter + alpha/beta pass ---------
+        parts = [S.partition_nnz(rp, world, q) for q in range(world)]
+        starts = [p_["start_row"] for p_ in parts]
+        nrows = [len(p_["rowptr"]) - 1 for p_ in parts]
+        maxblk = max(max(nrows), 1) * n
+        mine = torch.zeros(maxblk, dtype=torch.float64, device=dev)           # packed m_i x n block (+ padding)
+        allb = torch.zeros(world * maxblk, dtype=torch.float64, device=dev)
+        C3 = torch.ones(rows * n, dtype=torch.float64, device=dev)
+        e3 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+
+        def step3(k=None):
+            if k is not None: e3[k][0].record()
+            S.dense_to_rowmajor(cols, n, B2, cols, Bt)
+            if m_i > 0:
+                S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 0.0, mine, m_i)   # beta = 0: no zero fill
+            if k is not None: e3[k][1].record()
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(allb, mine)        # half the bytes of the all-reduce
+            else:                                              # rehearsal: gloo on host copies
+                hs = [torch.empty(maxblk, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(hs, mine.cpu())
+                allb.copy_(torch.cat(hs))
+            if k is not None: e3[k][2].record()
+            S.merge_rowblocks_local(rows, n, starts, nrows, [allb[q * maxblk:(q + 1) * maxblk] for q in range(world)],
+                                    1.0, 1.0, C3)
+            if k is not None: e3[k][3].record()
+
+        for _ in range(args.warmup):
+            step3()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step3(k)
+        torch.cuda.synchronize()
+        barrier()
+        el3 = time.perf_counter() - t0
+        t = torch.tensor([el3], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el3 = float(t.item())
+        m3_ok = None
+        if rank == 0:
+            got3 = C3.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
+            m3_ok = bool(np.allclose(got3, want2, rtol=1e-9, atol=1e-9))
+            if not m3_ok:
+                raise SystemExit("method-2 (row-block merge) bench result does not match the oracle: max diff %g" % np.abs(got3 - want2).max())
+        out["method2_rowblocks"] = {
+            "oracle_check": m3_ok, "scaling": "strong", "n_total_cols": n,
+            "gflops": round(flops_step * args.steps / el3 / 1e9, 2), "ms_per_step": round(el3 / args.steps * 1e3, 5),
+            "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e3])), 5),
+            "ms_allgather": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e3])), 5),
+            "ms_merge": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e3])), 5),
+            "allgather_payload_bytes_per_rank": maxblk * 8,
+            "note": "packed row blocks (beta = 0), torch.distributed all_gather_into_tensor (RCCL), "
+                    "sblas_hip_merge_rowblocks_local_f64; the C++ API does the same with RCCL send/recv",
+        }
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(rows, cols, n, rp, ci, v, Bh.numpy(), args.cpu_seconds)
     elif rank == 0:

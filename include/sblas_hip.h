@@ -118,6 +118,24 @@ void sblas_hip_comm_release_all(void);
 int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void *const *streams,
                                 int64_t count);
 
+/* Method-2 / SpMV merge without the all-reduce (fast path for spmm.h:222-283 and spmv.h:60-138: the zero-filled
+ * M x N `C_copy`, the ncclAllReduce over all of it and the axpby launch).  The partial results of the nnz row-block
+ * partition (matrix.h:356-395) are disjoint except for the rows a block boundary cuts, so rank q computes only its
+ * own rows into a PACKED buffer partial[q] (num_rows[q] x N, column-major, leading dimension num_rows[q];
+ * start_row[q] = starting_row_gpu[q], num_rows[q] = get_gpu_row_ptr_num(q) - 1), every rank receives the other
+ * ranks' packed blocks into gather[r] (room for the sum of all blocks; own block is not copied) over RCCL
+ * send/recv -- half the xGMI bytes of the all-reduce, no redundant adds -- and one kernel per rank does
+ *   C_r[i, j] = beta * C_r[i, j] + alpha * sum_{q : row i in block q} partial_q[i - start_row[q], j].
+ * Ranks folded onto one device skip the copies.  Stream-ordered after each rank's producers; never synchronises. */
+int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, const int64_t *start_row,
+                                  const int64_t *num_rows, double *const *partial, double *const *gather,
+                                  double alpha, double beta, double *const *C, int64_t ldc, void *const *streams);
+/* The scatter + alpha/beta pass alone, for callers that moved the blocks themselves (torch.distributed, MPI ...):
+ * src[q] are g packed blocks resident on `device`. */
+int sblas_hip_merge_rowblocks_local_f64(int device, void *stream, int64_t M, int64_t N, int g,
+                                        const int64_t *start_row, const int64_t *num_rows,
+                                        const double *const *src, double alpha, double beta, double *C, int64_t ldc);
+
 /* ---------------------------------------------------------------------------------------
  * Host-side placement arithmetic (pure functions, no GPU needed).
  * ------------------------------------------------------------------------------------- */

@@ -19,6 +19,7 @@ typedef void *rcclComm_t;
 typedef int (*fn_CommInitAll)(rcclComm_t *, int, const int *);
 typedef int (*fn_CommDestroy)(rcclComm_t);
 typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t);
+typedef int (*fn_SendRecv)(void *, size_t, int, int, rcclComm_t, hipStream_t); // ncclSend / ncclRecv (rccl.h)
 typedef int (*fn_Group)(void);
 constexpr int RCCL_FLOAT64 = 8; // ncclFloat64 / ncclDouble, rccl.h:467
 constexpr int RCCL_SUM = 0;     // ncclSum, rccl.h:448
@@ -28,6 +29,7 @@ struct Rccl {
     fn_CommInitAll CommInitAll = nullptr;
     fn_CommDestroy CommDestroy = nullptr;
     fn_AllReduce AllReduce = nullptr;
+    fn_SendRecv Send = nullptr, Recv = nullptr;
     fn_Group GroupStart = nullptr, GroupEnd = nullptr;
     bool ok = false;
 };
@@ -46,9 +48,11 @@ Rccl &rccl()
         r.CommInitAll = (fn_CommInitAll)dlsym(r.handle, "ncclCommInitAll");
         r.CommDestroy = (fn_CommDestroy)dlsym(r.handle, "ncclCommDestroy");
         r.AllReduce = (fn_AllReduce)dlsym(r.handle, "ncclAllReduce");
+        r.Send = (fn_SendRecv)dlsym(r.handle, "ncclSend");
+        r.Recv = (fn_SendRecv)dlsym(r.handle, "ncclRecv");
         r.GroupStart = (fn_Group)dlsym(r.handle, "ncclGroupStart");
         r.GroupEnd = (fn_Group)dlsym(r.handle, "ncclGroupEnd");
-        r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart && r.GroupEnd;
+        r.ok = r.CommInitAll && r.CommDestroy && r.AllReduce && r.Send && r.Recv && r.GroupStart && r.GroupEnd;
     });
     return r;
 }
@@ -161,6 +165,86 @@ extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void
                             streams ? (hipStream_t)streams[i] : nullptr) != 0) { rc = SBLAS_E_RCCL; break; }
         }
         if (r.GroupEnd() != 0 && rc == SBLAS_OK) rc = SBLAS_E_RCCL;
+    }
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int sblas_hip_merge_rowblocks_local_f64(int device, void *stream, int64_t M, int64_t N, int g,
+                                                   const int64_t *start_row, const int64_t *num_rows,
+                                                   const double *const *src, double alpha, double beta, double *C,
+                                                   int64_t ldc)
+{
+    if (M < 0 || N < 0 || g <= 0 || g > sblas::MAX_REPLICAS || !start_row || !num_rows || !src || ldc < M) return SBLAS_E_INVALID;
+    if (M == 0 || N == 0) return SBLAS_OK;
+    if (!C) return SBLAS_E_INVALID;
+    for (int q = 0; q < g; ++q) {
+        if (num_rows[q] < 0 || start_row[q] < 0 || start_row[q] + num_rows[q] > M) return SBLAS_E_INVALID;
+        if (num_rows[q] > 0 && !src[q]) return SBLAS_E_INVALID;
+    }
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_merge_rowblocks((hipStream_t)stream, M, N, g, src, start_row, num_rows, alpha, beta, C, ldc) ==
+                   hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+extern "C" int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, const int64_t *start_row,
+                                             const int64_t *num_rows, double *const *partial, double *const *gather,
+                                             double alpha, double beta, double *const *C, int64_t ldc,
+                                             void *const *streams)
+{
+    if (!comm || !start_row || !num_rows || !partial || !C || M < 0 || N < 0 || ldc < M) return SBLAS_E_INVALID;
+    if (M == 0 || N == 0) return SBLAS_OK;
+    CommSet &s = *static_cast<CommSet *>(comm);
+    const int g = (int)s.devs.size();
+    for (int q = 0; q < g; ++q) {
+        if (num_rows[q] < 0 || start_row[q] < 0 || start_row[q] + num_rows[q] > M || !C[q]) return SBLAS_E_INVALID;
+        if (num_rows[q] > 0 && !partial[q]) return SBLAS_E_INVALID;
+    }
+    const bool exchange = g > 1 && !s.one_device;
+    if (exchange && !gather) return SBLAS_E_INVALID;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = SBLAS_OK;
+    std::vector<size_t> off(g + 1, 0); // packed blocks back to back in every gather buffer
+    for (int q = 0; q < g; ++q) off[q + 1] = off[q] + (size_t)num_rows[q] * (size_t)N;
+    if (s.one_device && g > 1) {
+        // all ranks on one device: every rank's merge must see every rank's block -> order each stream after all
+        if (hipSetDevice(s.devs[0]) != hipSuccess) return SBLAS_E_HIP;
+        for (int i = 0; i < g && rc == SBLAS_OK; ++i)
+            if (hipEventRecord(s.events[i], streams ? (hipStream_t)streams[i] : nullptr) != hipSuccess) rc = SBLAS_E_HIP;
+        for (int i = 0; i < g && rc == SBLAS_OK; ++i)
+            for (int q = 0; q < g && rc == SBLAS_OK; ++q)
+                if (q != i && hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, s.events[q], 0) != hipSuccess)
+                    rc = SBLAS_E_HIP;
+    } else if (exchange) {
+        Rccl &r = rccl();
+        if (!r.ok) return SBLAS_E_RCCL;
+        for (int i = 0; i < g; ++i)
+            if (!gather[i]) return SBLAS_E_INVALID;
+        // all-to-all of the packed blocks: point-to-point transfers over the xGMI mesh, one group
+        if (r.GroupStart() != 0) return SBLAS_E_RCCL;
+        for (int i = 0; i < g && rc == SBLAS_OK; ++i) {
+            if (hipSetDevice(s.devs[i]) != hipSuccess) { rc = SBLAS_E_HIP; break; }
+            hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
+            for (int q = 0; q < g && rc == SBLAS_OK; ++q) {
+                if (q == i) continue;
+                const size_t mine = (size_t)num_rows[i] * (size_t)N, theirs = (size_t)num_rows[q] * (size_t)N;
+                if (mine && r.Send(partial[i], mine, RCCL_FLOAT64, q, s.comms[i], si) != 0) rc = SBLAS_E_RCCL;
+                if (theirs && rc == SBLAS_OK && r.Recv(gather[i] + off[q], theirs, RCCL_FLOAT64, q, s.comms[i], si) != 0)
+                    rc = SBLAS_E_RCCL;
+            }
+        }
+        if (r.GroupEnd() != 0 && rc == SBLAS_OK) rc = SBLAS_E_RCCL;
+    }
+    for (int i = 0; i < g && rc == SBLAS_OK; ++i) {
+        if (hipSetDevice(s.devs[i]) != hipSuccess) { rc = SBLAS_E_HIP; break; }
+        const double *src[sblas::MAX_REPLICAS];
+        for (int q = 0; q < g; ++q) src[q] = (q == i || !exchange) ? partial[q] : gather[i] + off[q];
+        if (sblas::launch_merge_rowblocks(streams ? (hipStream_t)streams[i] : nullptr, M, N, g, src, start_row, num_rows,
+                                          alpha, beta, C[i], ldc) != hipSuccess)
+            rc = SBLAS_E_HIP;
     }
     (void)hipSetDevice(prev);
     return rc;

@@ -2772,6 +2772,34 @@ __global__ __launch_bounds__(256) void sum_replicas_kernel(ReplicaPtrs bufs, int
     }
 }
 
+// Method-2 merge without an all-reduce.  The partial results of the row-block scheme are disjoint
+// except for the rows a block boundary cuts, so every GPU only needs the OTHER GPUs' blocks (packed, m_q x N,
+// leading dimension m_q) and one pass that scatters them into place and applies alpha / beta:
+//   C[r, j] = beta * C[r, j] + alpha * sum over the blocks q that contain row r of src_q[r - start_q, j]
+// (a boundary row gets two terms, a row longer than nnz/g more).  Replaces the M x N zero fill, the all-reduce of
+// the full M x N buffer and the axpby pass of spmm.h:222-283 / spmv.h:60-138.
+struct RowBlocks {
+    const double *src[MAX_REPLICAS];
+    long long start[MAX_REPLICAS];
+    long long nrows[MAX_REPLICAS];
+};
+__global__ __launch_bounds__(256) void merge_rowblocks_kernel(long long M, long long N, int g, RowBlocks b, double alpha,
+                                                             double beta, double *__restrict__ C, long long ldc)
+{
+    const long long total = M * N, stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long r = i % M, j = i / M;
+        double s = 0.0;
+        for (int q = 0; q < g; ++q) {
+            const long long rel = r - b.start[q];
+            if (rel >= 0 && rel < b.nrows[q]) s += b.src[q][j * b.nrows[q] + rel];
+        }
+        double *dst = C + j * ldc + r;
+        const double res = alpha * s;
+        *dst = (beta == 0.0) ? res : fma(beta, *dst, res);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -3062,6 +3090,21 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y)
 {
     hipLaunchKernelGGL(axpby_kernel, dim3(capped_grid(n, 512)), dim3(256), 0, s, n, alpha, x, beta, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_rowblocks(hipStream_t s, int64_t M, int64_t N, int g, const double *const *src,
+                                  const int64_t *start, const int64_t *nrows, double alpha, double beta, double *C,
+                                  int64_t ldc)
+{
+    RowBlocks b{};
+    for (int q = 0; q < g; ++q) {
+        b.src[q] = src[q];
+        b.start[q] = start[q];
+        b.nrows[q] = nrows[q];
+    }
+    hipLaunchKernelGGL(merge_rowblocks_kernel, dim3(capped_grid(M * N, 256)), dim3(256), 0, s, (long long)M,
+                       (long long)N, g, b, alpha, beta, C, (long long)ldc);
     return hipGetLastError();
 }
 

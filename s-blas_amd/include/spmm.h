@@ -15,6 +15,9 @@
 #include <assert.h>
 #include <iostream>
 #include <type_traits>
+#include <algorithm>
+#include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "matrix.h"
@@ -127,39 +130,75 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     void *comm = NULL;
     sblas_rt::must_sblas(sblas_hip_comm_get((int)n_gpu, devs.data(), &comm), "sblas_hip_comm_get");
 
-    // zeroed partial-result buffers, on the device (the reference uploads M*N zeros from the host)
-    std::vector<double *> ccopy(n_gpu, (double *)NULL);
+    // Merge.  Default: the row blocks are disjoint except for the rows a block boundary cuts, so every GPU computes
+    // its own rows into a packed buffer, the blocks are exchanged point to point and one pass scatters them and
+    // applies alpha / beta (sblas_hip_merge_rowblocks_f64: half the xGMI bytes of the all-reduce, no M*N zero fill,
+    // no separate axpby).  SBLAS_MERGE=allreduce keeps the reference's pattern (spmm.h:222-283): zeroed M*N C_copy,
+    // in-place sum all-reduce, axpby.
+    const char *merge_mode = getenv("SBLAS_MERGE");
+    const bool use_allreduce = merge_mode && !strcmp(merge_mode, "allreduce");
+    std::vector<double *> ccopy(n_gpu, (double *)NULL), gather(n_gpu, (double *)NULL);
     std::vector<void *> streams(n_gpu);
     std::vector<GPU_Timer *> timers(n_gpu);
+    std::vector<int64_t> starts(n_gpu), nrows(n_gpu);
+    size_t all_blocks = 0;
+    for (unsigned i = 0; i < n_gpu; ++i) {
+        starts[i] = (int64_t)pA->starting_row_gpu[i];
+        nrows[i] = (int64_t)pA->get_gpu_row_ptr_num(i) - 1;
+        all_blocks += (size_t)nrows[i] * (size_t)N;
+    }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         streams[i] = sblas_rt::stream(i);
-        SAFE_ALOC_GPU(ccopy[i], cnt * sizeof(double));
-        CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(double), (hipStream_t)streams[i]));
-        const int64_t m_i = (int64_t)pA->get_gpu_row_ptr_num(i) - 1;
+        const int64_t m_i = nrows[i];
         const int64_t nnz_i = (int64_t)pA->nnz_gpu[i];
         const size_t ws_bytes = sblas_hip_spmm_csr_f64_i32_workspace(m_i, K, nnz_i, N);
         void *ws = sblas_rt::workspace(i, ws_bytes);
-        // A_i * B accumulated (alpha = beta = 1) into the zero buffer at its row offset, ld = M
-        sblas_rt::must_sblas(
-            sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
-                                       (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
-                                       (const double *)pB->val_gpu[i], K, N, 1.0, 1.0,
-                                       ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
-            "sblas_hip_spmm_csr_f64_i32");
+        if (use_allreduce) {
+            // zeroed partial-result buffer on the device (the reference uploads M*N zeros from the host);
+            // A_i * B accumulated (alpha = beta = 1) at its row offset, ld = M
+            SAFE_ALOC_GPU(ccopy[i], cnt * sizeof(double));
+            CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(double), (hipStream_t)streams[i]));
+            sblas_rt::must_sblas(
+                sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
+                                           (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
+                                           (const double *)pB->val_gpu[i], K, N, 1.0, 1.0,
+                                           ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
+                "sblas_hip_spmm_csr_f64_i32");
+        } else {
+            // packed m_i x N block, beta = 0: nothing to clear
+            SAFE_ALOC_GPU(ccopy[i], std::max<size_t>((size_t)m_i * (size_t)N, 1) * sizeof(double));
+            SAFE_ALOC_GPU(gather[i], std::max<size_t>(all_blocks, 1) * sizeof(double));
+            sblas_rt::must_sblas(
+                sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
+                                           (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
+                                           (const double *)pB->val_gpu[i], K, N, 1.0, 0.0, ccopy[i], m_i, ws, ws_bytes),
+                "sblas_hip_spmm_csr_f64_i32");
+        }
         timers[i] = new GPU_Timer((hipStream_t)streams[i]);
         timers[i]->start_timer();
     }
-    // merge: sum of the partial C over all GPUs (RCCL over xGMI; stream-ordered after each GPU's SpMM)
-    sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ccopy.data(), streams.data(), (int64_t)cnt),
-                         "sblas_hip_allreduce_sum_f64");
+    if (use_allreduce) {
+        // sum of the partial C over all GPUs (RCCL over xGMI; stream-ordered after each GPU's SpMM)
+        sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ccopy.data(), streams.data(), (int64_t)cnt),
+                             "sblas_hip_allreduce_sum_f64");
+    } else {
+        std::vector<double *> cptr(n_gpu);
+        for (unsigned i = 0; i < n_gpu; ++i) cptr[i] = (double *)pC->val_gpu[i];
+        sblas_rt::must_sblas(sblas_hip_merge_rowblocks_f64(comm, M, N, starts.data(), nrows.data(), ccopy.data(),
+                                                           gather.data(), (double)alpha, (double)beta, cptr.data(), M,
+                                                           streams.data()),
+                             "sblas_hip_merge_rowblocks_f64");
+    }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         timers[i]->stop_timer();
-        // C = beta*C + alpha*Ccopy, same stream: no host round trip between merge and epilogue
-        sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], (int64_t)cnt, (double)alpha, ccopy[i], (double)beta,
-                                                 (double *)pC->val_gpu[i]),
-                             "sblas_hip_axpby_f64");
+        if (use_allreduce) {
+            // C = beta*C + alpha*Ccopy, same stream: no host round trip between merge and epilogue
+            sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], (int64_t)cnt, (double)alpha, ccopy[i],
+                                                     (double)beta, (double *)pC->val_gpu[i]),
+                                 "sblas_hip_axpby_f64");
+        }
     }
     sblas_rt::sync_all(n_gpu);
     for (unsigned i = 0; i < n_gpu; ++i) {
@@ -167,6 +206,7 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         cout << "GPU-" << i << " NCCL Time: " << timers[i]->measure() << " ms." << std::endl;
         delete timers[i];
         SAFE_FREE_GPU(ccopy[i]);
+        if (gather[i]) SAFE_FREE_GPU(gather[i]);
     }
     CUDA_CHECK_ERROR();
 }

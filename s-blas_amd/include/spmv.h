@@ -8,6 +8,9 @@
 #include <assert.h>
 #include <iostream>
 #include <stdio.h>
+#include <algorithm>
+#include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "matrix.h"
@@ -47,32 +50,59 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
     void *comm = NULL;
     sblas_rt::must_sblas(sblas_hip_comm_get((int)n_gpu, devs.data(), &comm), "sblas_hip_comm_get");
 
-    std::vector<double *> ycopy(n_gpu, (double *)NULL);
+    // Merge as in sblas_spmm_csr_v2: packed row blocks + sblas_hip_merge_rowblocks_f64 by default,
+    // SBLAS_MERGE=allreduce for the reference's zero-filled y copy + all-reduce + axpby (spmv.h:60-138).
+    const char *merge_mode = getenv("SBLAS_MERGE");
+    const bool use_allreduce = merge_mode && !strcmp(merge_mode, "allreduce");
+    std::vector<double *> ycopy(n_gpu, (double *)NULL), gather(n_gpu, (double *)NULL);
     std::vector<void *> streams(n_gpu);
     std::vector<GPU_Timer *> timers(n_gpu);
+    std::vector<int64_t> starts(n_gpu), nrows(n_gpu);
+    size_t all_blocks = 0;
+    for (unsigned i = 0; i < n_gpu; ++i) {
+        starts[i] = (int64_t)pA->starting_row_gpu[i];
+        nrows[i] = (int64_t)pA->get_gpu_row_ptr_num(i) - 1;
+        all_blocks += (size_t)nrows[i];
+    }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         streams[i] = sblas_rt::stream(i);
-        SAFE_ALOC_GPU(ycopy[i], (size_t)M * sizeof(double));
-        CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(double), (hipStream_t)streams[i]));
-        const int64_t m_i = (int64_t)pA->get_gpu_row_ptr_num(i) - 1;
+        const int64_t m_i = nrows[i];
+        if (use_allreduce) {
+            SAFE_ALOC_GPU(ycopy[i], (size_t)M * sizeof(double));
+            CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(double), (hipStream_t)streams[i]));
+        } else {
+            SAFE_ALOC_GPU(ycopy[i], std::max<size_t>((size_t)m_i, 1) * sizeof(double));
+            SAFE_ALOC_GPU(gather[i], std::max<size_t>(all_blocks, 1) * sizeof(double));
+        }
         sblas_rt::must_sblas(
             sblas_hip_spmv_csr_f64_i32(-1, streams[i], m_i, K, (int64_t)pA->nnz_gpu[i],
                                        (const int32_t *)pA->csrRowPtr_gpu[i], (const int32_t *)pA->csrColIdx_gpu[i],
-                                       (const double *)pA->csrVal_gpu[i], (const double *)pB->val_gpu[i], 1.0, 1.0,
-                                       ycopy[i] + (size_t)pA->starting_row_gpu[i]),
+                                       (const double *)pA->csrVal_gpu[i], (const double *)pB->val_gpu[i], 1.0,
+                                       use_allreduce ? 1.0 : 0.0,
+                                       use_allreduce ? ycopy[i] + (size_t)pA->starting_row_gpu[i] : ycopy[i]),
             "sblas_hip_spmv_csr_f64_i32");
         timers[i] = new GPU_Timer((hipStream_t)streams[i]);
         timers[i]->start_timer();
     }
-    sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ycopy.data(), streams.data(), M),
-                         "sblas_hip_allreduce_sum_f64");
+    if (use_allreduce) {
+        sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ycopy.data(), streams.data(), M),
+                             "sblas_hip_allreduce_sum_f64");
+    } else {
+        std::vector<double *> yptr(n_gpu);
+        for (unsigned i = 0; i < n_gpu; ++i) yptr[i] = (double *)pC->val_gpu[i];
+        sblas_rt::must_sblas(sblas_hip_merge_rowblocks_f64(comm, M, 1, starts.data(), nrows.data(), ycopy.data(),
+                                                           gather.data(), (double)alpha, (double)beta, yptr.data(), M,
+                                                           streams.data()),
+                             "sblas_hip_merge_rowblocks_f64");
+    }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         timers[i]->stop_timer();
-        sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], M, (double)alpha, ycopy[i], (double)beta,
-                                                 (double *)pC->val_gpu[i]),
-                             "sblas_hip_axpby_f64");
+        if (use_allreduce)
+            sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], M, (double)alpha, ycopy[i], (double)beta,
+                                                     (double *)pC->val_gpu[i]),
+                                 "sblas_hip_axpby_f64");
     }
     sblas_rt::sync_all(n_gpu);
     for (unsigned i = 0; i < n_gpu; ++i) {
@@ -80,6 +110,7 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
         cout << "GPU-" << i << " NCCL Time: " << timers[i]->measure() << " ms." << std::endl;
         delete timers[i];
         SAFE_FREE_GPU(ycopy[i]);
+        if (gather[i]) SAFE_FREE_GPU(gather[i]);
     }
     CUDA_CHECK_ERROR();
 }

@@ -20,6 +20,7 @@ EXPORTS = [
     "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
     "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_spmm_cycle_stamps", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
+    "sblas_hip_merge_rowblocks_f64", "sblas_hip_merge_rowblocks_local_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
     "sblas_mm_read_info", "sblas_mm_read_csr",
 ]
@@ -72,6 +73,12 @@ def lib():
     L.sblas_hip_comm_release_all.restype = None
     L.sblas_hip_allreduce_sum_f64.restype = C.c_int
     L.sblas_hip_allreduce_sum_f64.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), i64]
+    L.sblas_hip_merge_rowblocks_f64.restype = C.c_int
+    L.sblas_hip_merge_rowblocks_f64.argtypes = [vp, i64, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                                f64, f64, C.POINTER(vp), i64, C.POINTER(vp)]
+    L.sblas_hip_merge_rowblocks_local_f64.restype = C.c_int
+    L.sblas_hip_merge_rowblocks_local_f64.argtypes = [C.c_int, vp, i64, i64, C.c_int, C.POINTER(i64), C.POINTER(i64),
+                                                      C.POINTER(vp), f64, f64, vp, i64]
     L.sblas_find_row_of_nnz.restype = i32
     L.sblas_find_row_of_nnz.argtypes = [vp, i32, i32]
     L.sblas_partition_nnz.restype = i64
@@ -211,6 +218,22 @@ def spmv(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offs
         _dev_ptr(val, torch.float64, "val") if nnz else None,
         _dev_ptr(x, torch.float64, "x"), alpha, beta, _dev_ptr(y, torch.float64, "y") + 8 * y_offset)
     check(rc, "sblas_hip_spmv_csr_f64_i32")
+
+
+def merge_rowblocks_local(M, N, starts, nrows, blocks, alpha, beta, Cmat, ldc=None, stream=None):
+    """C = beta*C + alpha * (packed row blocks scattered into place), sblas_hip_merge_rowblocks_local_f64.
+    blocks[q]: flat float64 device tensor holding an nrows[q] x N column-major block (leading dimension nrows[q])."""
+    import torch
+    g = len(blocks)
+    st = (C.c_int64 * g)(*[int(v) for v in starts])
+    nr = (C.c_int64 * g)(*[int(v) for v in nrows])
+    for q in range(g):
+        if blocks[q] is not None and blocks[q].numel() < int(nrows[q]) * N:
+            raise SblasError("block %d is smaller than nrows x N" % q)
+    ptrs = (C.c_void_p * g)(*[_dev_ptr(b, torch.float64, "block") if b is not None and b.numel() else None for b in blocks])
+    pc = _dev_ptr(Cmat, torch.float64, "C")
+    check(lib().sblas_hip_merge_rowblocks_local_f64(-1, _stream(stream), M, N, g, st, nr, ptrs, alpha, beta, pc,
+                                                    M if ldc is None else ldc), "sblas_hip_merge_rowblocks_local_f64")
 
 
 def axpby(n, alpha, x, beta, y, stream=None):

@@ -271,6 +271,60 @@ def test_method2_row_blocks_merge_and_epilogue(env, ash85, g):
     assert close(C.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("g", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("case", ["ash85", "long_row"])
+def test_method2_rowblock_merge_fast_path(env, ash85, g, case):
+    """the same method-2 result without the M x N zero fill, the all-reduce and the axpby pass: every
+    block computes its own rows into a packed buffer (beta = 0, ldc = rows of the block) and
+    sblas_hip_merge_rowblocks_local_f64 scatters the blocks and applies alpha / beta.  `long_row`: one row holds
+    half of the nonzeros, so it is cut into pieces on several blocks (more than two terms for that row)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    if case == "ash85":
+        M = K = 85
+        rp, ci, v = ash85["rowptr"], ash85["colidx"], ash85["val"]
+    else:
+        M, K = 300, 2000
+        rp, ci, v = synth.random_csr(M, K, 6, seed=5, long_row=(150, 1800), sorted_rows=True)
+    N = 24
+    rng = np.random.default_rng(3)
+    Bh, C0 = rng.standard_normal(K * N), rng.standard_normal(M * N)
+    B = torch.from_numpy(Bh).to(dev)
+    blocks, starts, nrows = [], [], []
+    for i in range(g):
+        d = sblas.partition_nnz(rp, g, i)
+        lo, k = d["first_nnz"], d["nnz"]
+        m_i = len(d["rowptr"]) - 1
+        starts.append(d["start_row"])
+        nrows.append(m_i)
+        blk = torch.full((max(m_i * N, 1),), 7.0, dtype=torch.float64, device=dev)   # junk: beta = 0 must not read it
+        if m_i > 0:
+            Ai = Dev(torch, dev, d["rowptr"], ci[lo:lo + k], v[lo:lo + k], K)
+            ws = torch.empty(sblas.spmm_workspace_bytes(m_i, K, k, N) // 8, dtype=torch.float64, device=dev)
+            sblas.spmm(m_i, K, Ai.rowptr, Ai.colidx, Ai.val, B, K, N, 1.0, 0.0, blk, m_i, ws)
+        blocks.append(blk)
+    C = torch.from_numpy(C0.copy()).to(dev)
+    sblas.merge_rowblocks_local(M, N, starts, nrows, blocks, 3.0, 4.0, C)
+    ref = oracle.spmm(M, K, N, rp, ci, v, Bh, C0.copy(), 3.0, 4.0)
+    assert close(C.cpu().numpy(), ref)
+    # N = 1 (the SpMV merge) with beta = 0
+    xh = rng.standard_normal(K)
+    x = torch.from_numpy(xh).to(dev)
+    parts = []
+    for i in range(g):
+        d = sblas.partition_nnz(rp, g, i)
+        lo, k = d["first_nnz"], d["nnz"]
+        m_i = len(d["rowptr"]) - 1
+        yb = torch.zeros(max(m_i, 1), dtype=torch.float64, device=dev)
+        if m_i > 0:
+            Ai = Dev(torch, dev, d["rowptr"], ci[lo:lo + k], v[lo:lo + k], K)
+            sblas.spmv(m_i, K, Ai.rowptr, Ai.colidx, Ai.val, x, 1.0, 0.0, yb)
+        parts.append(yb)
+    y = torch.full((M,), float("nan"), dtype=torch.float64, device=dev)
+    sblas.merge_rowblocks_local(M, 1, starts, nrows, parts, 2.0, 0.0, y)
+    assert close(y.cpu().numpy(), oracle.spmv(M, rp, ci, v, xh, np.zeros(M), 2.0, 0.0))
+
+
 @pytest.mark.parametrize("avg", [1, 3, 7, 15, 30, 70, 400])
 def test_spmv_every_row_length_class(env, avg):
     """One case per lanes-per-row instantiation (4..64), unsorted rows, empty rows, a long row."""
