@@ -129,8 +129,8 @@ size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t 
     // row panel (the panel classifier's verdicts)
     const int64_t w = spmm_chunk_cols(cols, n);
     const size_t bt = ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(w) * sizeof(double);
-    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_WINDOW2_PANEL_ROWS - 1) / sblas::SPMM_WINDOW2_PANEL_ROWS;
-    return bt + panels * 8 + 16;
+    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_MIN_PANEL_ROWS - 1) / sblas::SPMM_MIN_PANEL_ROWS;
+    return bt + panels * 8 + 16; // + one spare entry and the widest-span slot read by the direct kernel
 }
 
 int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n, const double *B,

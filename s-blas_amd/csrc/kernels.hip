@@ -588,6 +588,9 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len && !tail &&
                         (float)nnz >= min_density * (float)(last - first + 1);
         info[p] = ok ? make_int2(first, last) : make_int2(1, 0);
+        // widest column span of any panel (slot after the verdicts, zeroed by the launcher): the direct kernel picks
+        // its panel -> XCD map from it
+        if (last >= first) atomicMax(&info[npanels].x, last - first + 1);
     }
 }
 
@@ -1900,6 +1903,7 @@ __global__ __launch_bounds__(1024) void spmm_window5_kernel(
 //     unit only sees the largest count of the four rows, which sets the number of 4-step blocks to run.
 // The instruction mix of a step is unchanged (v_add_u32_dpp, two ds_read_b128, four v_fmac_f64_dpp).
 // ---------------------------------------------------------------------------------------------
+static_assert(4 * 4 * 2 >= SPMM_MIN_PANEL_ROWS, "the workspace reserves one verdict per SPMM_MIN_PANEL_ROWS rows");
 constexpr int W6_GMAX = 3;                   // groups of four rows per wave: 2 or 3 (template parameter)
 
 
@@ -2216,14 +2220,24 @@ template <bool HALF>
 __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows)
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave)
 {
     constexpr int TILE_COLS = HALF ? 64 : 128;
     constexpr int PER_STEP = HALF ? 32 : 16; // nonzeros handled by one 16-slot sweep
     __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
-    const int row0 = xcd_contiguous_panel(blockIdx.x, npanels) * WIDE_PANEL;
+    // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
+    // bands: the band must fit the Infinity Cache once, not once per XCD); otherwise one contiguous range per XCD
+    // (`interleave` < 0: decide from the widest panel span the classifier recorded -- a band of B rows wider than 16 MB)
+    if (interleave < 0) {
+        interleave = 0;
+        if (info != nullptr) {
+            const int widest = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+            interleave = (long long)widest * (HALF ? 512 : 1024) > (16ll << 20);
+        }
+    }
+    const int row0 = (interleave ? (int)blockIdx.x : xcd_contiguous_panel(blockIdx.x, npanels)) * WIDE_PANEL;
     const int col0 = blockIdx.y * TILE_COLS;
     const int row = row0 + wave;
     // rows of panels that the windowed kernel owns are skipped (wave-uniform: one row per wave)
@@ -2875,6 +2889,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+                (void)hipMemsetAsync(winfo + np, 0, sizeof(int2), s);
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
                                    np, info_rows, rowptr, colidx, (gen4 || gen5 || gen6) ? 0x7fffffff : ch * 64,
                                    /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
@@ -2948,14 +2963,22 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 info = winfo;
             }
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
+            // experiments: unused dynamic LDS limits the resident workgroups per CU (rows in flight vs L2 reach)
+            const char *dl = getenv("SBLAS_DIRECT_LDS");
+            // 128-column tiles: one workgroup per CU (Queen-like rows at N = 256: +13 %, banded matrix at N = 128: +3 %)
+            const size_t pad = dl ? (size_t)atoi(dl) : (ldbt == 64 ? 0 : 90000);
+            const char *dm = getenv("SBLAS_DIRECT_MAP"); /* experiments: interleave | contiguous; default: by span */
+            const int interleave = (dm && !strcmp(dm, "interleave")) ? 1 : (dm && !strcmp(dm, "contiguous")) ? 0 : -1;
             if (ldbt == 64) {
                 dim3 grid((unsigned)wide_panels, 1u);
-                hipLaunchKernelGGL(spmm_direct_dpp_kernel<true>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows);
+                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<true>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
             } else {
                 dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 128));
-                hipLaunchKernelGGL(spmm_direct_dpp_kernel<false>, grid, dim3(WIDE_WAVES * 64), 0, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows);
+                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<false>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
             }
         } else if (variant == SPMM_VARIANT_DIRECT) {
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;

@@ -174,7 +174,7 @@ def test_argument_validation_returns_codes_without_a_gpu(sblas):
     assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8 + 1 * 8 + 16   # Bt + zero row, panel verdicts
     assert b"workspace" in L.sblas_hip_error_string(3)
     # Queen_4147-sized B at N = 256 (8.5 GB row-major) is walked in 128-column chunks: workspace = one chunk
-    assert L.sblas_hip_spmm_csr_f64_i32_workspace(4147110, 4147110, 316548962, 256) == 4147111 * 128 * 8 + ((4147110 + 35) // 36) * 8 + 16
+    assert L.sblas_hip_spmm_csr_f64_i32_workspace(4147110, 4147110, 316548962, 256) == 4147111 * 128 * 8 + ((4147110 + 31) // 32) * 8 + 16
     # the stage-2-only entry point cannot chunk: a Bt beyond the 32-bit offset window is refused
     assert L.sblas_hip_spmm_csr_rowmajorB_f64_i32(-1, None, 10, 4147110, 5, one, one, one, one, 256, 256, 1.0, 0.0, one, 10) == 1
 
