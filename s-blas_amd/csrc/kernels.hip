@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include <string.h>
 #include "kernels.h"
@@ -44,19 +45,25 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
     __shared__ double tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t k0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
-#pragma unroll 4
-    for (int jj = ty; jj < 64; jj += 4) {
-        const int64_t j = j0 + jj, k = k0 + tx;
-        double v = 0.0;
-        if (j < n && k < cols) v = B[k + j * ldb];
-        tile[jj][tx] = v;
+    // all sixteen loads of a thread in flight before the first LDS store (the kernel is latency-bound otherwise:
+    // 2.96 TB/s with four at a time)
+    double v[16];
+    const int64_t k = k0 + tx;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int64_t j = j0 + ty + 4 * u;
+        v[u] = (j < n && k < cols) ? B[k + j * ldb] : 0.0;
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = v[u];
     __syncthreads();
-#pragma unroll 4
-    for (int kk = ty; kk < 64; kk += 4) {
-        const int64_t k = k0 + kk, j = j0 + tx;
-        if (k < cols && j < ldbt) Bt[k * ldbt + j] = tile[tx][kk];
-        if (k == cols && j < ldbt) Bt[k * ldbt + j] = 0.0; // the all-zero row masked DPP slots point at
+    const int64_t j = j0 + tx;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int kk = ty + 4 * u;
+        const int64_t kr = k0 + kk;
+        if (kr < cols && j < ldbt) Bt[kr * ldbt + j] = tile[tx][kk];
+        if (kr == cols && j < ldbt) Bt[kr * ldbt + j] = 0.0; // the all-zero row masked DPP slots point at
     }
 }
 
@@ -2237,6 +2244,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
             interleave = (long long)widest * (HALF ? 512 : 1024) > (16ll << 20);
         }
     }
+    // (a persistent form -- a few workgroups per CU walking the panels, two scalar loads per skipped panel -- was tried
+    //  to make the all-windowed case cheaper: the direct case lost 10-15 % to the static assignment, no gain overall)
     const int row0 = (interleave ? (int)blockIdx.x : xcd_contiguous_panel(blockIdx.x, npanels)) * WIDE_PANEL;
     const int col0 = blockIdx.y * TILE_COLS;
     const int row = row0 + wave;
