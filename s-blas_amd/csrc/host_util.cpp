@@ -249,6 +249,68 @@ int parse_file(const char *path, Parsed &out)
     return SBLAS_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Binary sidecar cache: with SBLAS_CSR_CACHE=1 a parsed matrix is written next to its source as
+// <path>.csrbin and read back on later loads when the source's size and mtime still match -- the text parse of a
+// Queen_4147-sized file takes minutes, the binary read seconds.  The arrays are the loader's own output, so the
+// result is bit-identical by construction (tests compare both ways).  Opt-in: it writes a file beside the input.
+// Layout: 8 x int64 header {magic, version, source size, source mtime_ns, rows, cols, nnz, mirrored},
+// rowptr[rows+1] int32, colidx[nnz] int32, (padding to 8 bytes,) val[nnz] fp64.
+// ------------------------------------------------------------------------------------------
+constexpr long long CSRBIN_MAGIC = 0x4e4942525343424cLL; // "LBCSRBIN" little endian
+constexpr long long CSRBIN_VERSION = 1;
+
+bool cache_enabled()
+{
+    const char *e = getenv("SBLAS_CSR_CACHE");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
+bool read_sidecar(const std::string &bin, long long size, long long mtime_ns, Parsed &out)
+{
+    FILE *f = fopen(bin.c_str(), "rb");
+    if (!f) return false;
+    long long h[8];
+    bool ok = fread(h, sizeof(long long), 8, f) == 8 && h[0] == CSRBIN_MAGIC && h[1] == CSRBIN_VERSION && h[2] == size &&
+              h[3] == mtime_ns && h[4] >= 0 && h[5] >= 0 && h[6] >= 0 && h[4] < 0x7fffffffLL && h[6] <= 0x7fffffffLL;
+    if (ok) {
+        out.rows = (int32_t)h[4];
+        out.cols = (int32_t)h[5];
+        out.nnz = (int32_t)h[6];
+        out.mirrored = (int32_t)h[7];
+        out.rowptr.resize((size_t)out.rows + 1);
+        out.colidx.resize((size_t)out.nnz);
+        out.val.resize((size_t)out.nnz);
+        const size_t ints = (size_t)out.rows + 1 + (size_t)out.nnz;
+        ok = fread(out.rowptr.data(), 4, out.rowptr.size(), f) == out.rowptr.size() &&
+             fread(out.colidx.data(), 4, out.colidx.size(), f) == out.colidx.size();
+        int32_t padw = 0;
+        if (ok && (ints & 1)) ok = fread(&padw, 4, 1, f) == 1;
+        ok = ok && fread(out.val.data(), 8, out.val.size(), f) == out.val.size();
+        // structural sanity: a truncated or foreign file must not reach the caller
+        ok = ok && out.rowptr[0] == 0 && out.rowptr[out.rows] == out.nnz;
+    }
+    fclose(f);
+    return ok;
+}
+
+void write_sidecar(const std::string &bin, const Parsed &p)
+{
+    const std::string tmp = bin + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return; // read-only directory: the cache is an optimisation, not a requirement
+    const long long h[8] = {CSRBIN_MAGIC, CSRBIN_VERSION, p.size, p.mtime_ns, p.rows, p.cols, p.nnz, p.mirrored};
+    const size_t ints = (size_t)p.rows + 1 + (size_t)p.nnz;
+    const int32_t padw = 0;
+    bool ok = fwrite(h, sizeof(long long), 8, f) == 8 && fwrite(p.rowptr.data(), 4, p.rowptr.size(), f) == p.rowptr.size() &&
+              fwrite(p.colidx.data(), 4, p.colidx.size(), f) == p.colidx.size();
+    if (ok && (ints & 1)) ok = fwrite(&padw, 4, 1, f) == 1;
+    ok = ok && fwrite(p.val.data(), 8, p.val.size(), f) == p.val.size();
+    ok = (fclose(f) == 0) && ok;
+    if (ok) ok = rename(tmp.c_str(), bin.c_str()) == 0;
+    if (!ok) remove(tmp.c_str());
+}
+
 // returns with g_cache_mu held by the caller
 int ensure_parsed(const char *path)
 {
@@ -257,8 +319,19 @@ int ensure_parsed(const char *path)
     const long long mt = (long long)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec;
     if (g_cache.size == (long long)st.st_size && g_cache.mtime_ns == mt && g_cache.path == path) return SBLAS_OK;
     Parsed fresh;
+    const bool use_cache = cache_enabled();
+    const std::string bin = std::string(path) + ".csrbin";
+    if (use_cache && read_sidecar(bin, (long long)st.st_size, mt, fresh)) {
+        fresh.path = path;
+        fresh.size = (long long)st.st_size;
+        fresh.mtime_ns = mt;
+        g_cache = std::move(fresh);
+        return SBLAS_OK;
+    }
+    fresh = Parsed();
     const int rc = parse_file(path, fresh);
     if (rc != SBLAS_OK) return rc;
+    if (use_cache) write_sidecar(bin, fresh);
     g_cache = std::move(fresh);
     return SBLAS_OK;
 }

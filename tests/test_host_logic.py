@@ -91,6 +91,43 @@ def test_loader_roundtrip_random(sblas, oracle, tmp_path):
             assert x.tobytes() == y.tobytes()
 
 
+def test_loader_binary_sidecar_cache(sblas, oracle, tmp_path, monkeypatch):
+    """with SBLAS_CSR_CACHE=1 the parsed arrays are written to <file>.csrbin and served from there while
+    the source's size and mtime are unchanged -- bit-identical to the text parse; a changed source or a damaged sidecar
+    falls back to parsing (and rewrites it); without the switch nothing is written."""
+    import os, shutil, time
+    src = os.path.join(os.path.dirname(__file__), "golden", "ash85.mtx")
+    p = tmp_path / "a.mtx"
+    shutil.copy(src, p)
+    ref = oracle.read_mtx(str(p))
+
+    def same(a):
+        return a[:4] == ref[:4] and all(x.tobytes() == y.tobytes() for x, y in zip(a[4:], ref[4:]))
+
+    monkeypatch.delenv("SBLAS_CSR_CACHE", raising=False)
+    assert same(sblas.read_mtx(str(p))) and not os.path.exists(str(p) + ".csrbin")
+    monkeypatch.setenv("SBLAS_CSR_CACHE", "1")
+    assert same(sblas.read_mtx(str(p)))                       # parse + write
+    bin_path = str(p) + ".csrbin"
+    assert os.path.exists(bin_path) and os.path.getsize(bin_path) == 64 + 4 * (86 + 523) + 4 + 8 * 523
+    # prove the second load is served by the sidecar: plant a recognisable value in it
+    raw = bytearray(open(bin_path, "rb").read())
+    off_val = 64 + 4 * (86 + 523) + 4
+    raw[off_val:off_val + 8] = np.float64(42.5).tobytes()
+    open(bin_path, "wb").write(raw)
+    got = sblas.read_mtx(str(p))
+    assert got[6][0] == 42.5 and got[4].tobytes() == ref[4].tobytes()
+    # a touched source invalidates it
+    time.sleep(0.01)
+    os.utime(p, None)
+    assert same(sblas.read_mtx(str(p)))
+    # a truncated sidecar is ignored and rewritten
+    open(bin_path, "wb").write(bytes(raw[:100]))
+    assert same(sblas.read_mtx(str(p)))
+    assert os.path.getsize(bin_path) == len(raw)
+    assert same(sblas.read_mtx(str(p)))
+
+
 def test_find_row_matches_linear_scan(sblas, oracle):
     rng = np.random.default_rng(1)
     lens = rng.integers(0, 5, 200)
