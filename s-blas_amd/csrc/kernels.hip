@@ -2428,6 +2428,64 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// SpMV for medium rows (25..96 nonzeros), segmented form.  With one row per wave a 73-nonzero row (Queen_4147) fills
+// 57 % of two 64-lane slices and walks two dependent trips: 2.3 TB/s.  Here a wave owns R consecutive rows -- one
+// contiguous run of nonzeros -- and streams it in unpredicated slices of 64 (clamped indices, S slices in flight:
+// 91 % of the lanes busy for R = 4, S = 5 at 73 per row); every lane knows the row of its entry from the R + 1 row
+// pointers (wave-uniform after a readlane), products are accumulated per row and folded once at the end: the
+// wave-level segmented reduction of the north star.
+// ---------------------------------------------------------------------------------------------
+template <int R, int S>
+__global__ __launch_bounds__(256) void spmv_csr_seg_kernel(int rows, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ colidx,
+                                                          const double *__restrict__ val,
+                                                          const double *__restrict__ x, double alpha, double beta,
+                                                          double *__restrict__ y)
+{
+    static_assert(R >= 1 && R <= 16, "row pointers are broadcast from the first R + 1 lanes");
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (r0 >= rows) return;
+    const int mine = rowptr[min(r0 + min(lane, R), rows)];
+    int b[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) b[i] = __builtin_amdgcn_readlane(mine, i);
+    const int p0 = b[0], p1 = b[R], last = p1 - 1;
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    for (int base = p0; base < p1; base += S * WAVE) {
+        int c[S];
+        double a[S], xv[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int p = min(base + u * WAVE + lane, last);
+            c[u] = colidx[p];
+            a[u] = val[p];
+        }
+#pragma unroll
+        for (int u = 0; u < S; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int idx = base + u * WAVE + lane;
+            const double prod = (idx <= last) ? a[u] * xv[u] : 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] += (idx >= b[i] && idx < b[i + 1]) ? prod : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        double sum = acc[i];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+        if (lane == i && r0 + i < rows) {
+            const double res = alpha * sum;
+            y[r0 + i] = (beta == 0.0) ? res : fma(beta, y[r0 + i], res);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SpMV for long rows, x window in LDS (second attempt).  Diagnostics on the plain kernel: the A stream alone runs at
 // 6.8 TB/s with the same row-per-wave shape (tools/stream_bench.hip), replacing the gather by a one-line read still
 // leaves 76 us -- what costs is the second, dependent vector-memory access per slice (address unit ~15 cycles per
@@ -3096,6 +3154,23 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     if (avg > 96.0 && sv && !strcmp(sv, "lds2")) SBLAS_SPMV_LDS(2, 7);
     if (avg > 96.0 && sv && !strcmp(sv, "lds2s4")) SBLAS_SPMV_LDS(2, 4);
     if (avg > 96.0 && sv && !strcmp(sv, "lds1s4")) SBLAS_SPMV_LDS(1, 4);
+#define SBLAS_SPMV_SEG(RV, SV)                                                                                       \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((spmv_csr_seg_kernel<RV, SV>), dim3((unsigned)((rows + 4 * RV - 1) / (4 * RV))), dim3(256), \
+                           0, s, rows, rowptr, colidx, val, x, alpha, beta, y);                                      \
+        return hipGetLastError();                                                                                    \
+    } while (0)
+    // medium rows: R rows per wave, segmented (Queen-like rows, 73 per row: 232 us vs 395 us; banded synthetic rows of
+    // 36 / 72 / 90: 122 / 266 / 351 us vs 150 / 339 / 375 us for the lanes-per-row kernel; below ~32 per row the
+    // lanes-per-row kernel wins)
+    if (!sv || !*sv || !strcmp(sv, "auto")) {
+        if (avg > 48.0 && avg <= 96.0) SBLAS_SPMV_SEG(4, 5);
+        if (avg > 32.0 && avg <= 48.0) SBLAS_SPMV_SEG(8, 5);
+    }
+    if (sv && !strcmp(sv, "seg4")) SBLAS_SPMV_SEG(4, 5);
+    if (sv && !strcmp(sv, "seg3")) SBLAS_SPMV_SEG(3, 4);
+    if (sv && !strcmp(sv, "seg8")) SBLAS_SPMV_SEG(8, 5);
+    if (sv && !strcmp(sv, "seg2")) SBLAS_SPMV_SEG(2, 3);
     if (sv && !strcmp(sv, "nogather")) { // diagnostics only
         hipLaunchKernelGGL((spmv_csr_kernel<64, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, rowptr,
                            colidx, val, x, alpha, beta, y);

@@ -562,7 +562,7 @@ def spmv_variant_env():
         os.environ["SBLAS_SPMV_VARIANT"] = old
 
 
-@pytest.mark.parametrize("variant", ["plain", "burst", "window", "flat2", "flat4", "flat8", "lds", "lds2", "lds2s4"])
+@pytest.mark.parametrize("variant", ["plain", "burst", "window", "flat2", "flat4", "flat8", "lds", "lds2", "lds2s4", "seg2", "seg3", "seg4", "seg8"])
 @pytest.mark.parametrize("kind", ["banded", "unsorted", "wide_span", "outliers"])
 def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
     """Long rows (the 64-lanes-per-row instantiation, unrolled four slices deep): banded, shuffled, very wide spans
@@ -593,6 +593,25 @@ def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
         sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
         ref = oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)
         assert close(y.cpu().numpy(), ref), (kind, alpha, beta)
+
+
+@pytest.mark.parametrize("variant", ["seg2", "seg3", "seg4", "seg8"])
+@pytest.mark.parametrize("avg", [2, 30, 73, 150])
+def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
+    """The segmented kernel (R rows per wave, one contiguous run of nonzeros, per-row accumulation by row pointer
+    comparison): empty rows, a row far longer than a burst, unsorted columns, row counts that are not a multiple of R."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    spmv_variant_env(variant)
+    M, K = 1237, 4000
+    rp, ci, v = synth.random_csr(M, K, avg, seed=avg, empty_every=7, long_row=(33, 3000))
+    A = Dev(torch, dev, rp, ci, v, K)
+    rng = np.random.default_rng(avg)
+    xh, yh = rng.standard_normal(K), rng.standard_normal(M)
+    for alpha, beta in ((1.0, 1.0), (2.0, 0.0)):
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
+        assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, avg, alpha, beta)
 
 
 @pytest.mark.parametrize("n", [64, 200, 256, 300])
