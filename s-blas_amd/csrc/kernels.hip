@@ -1965,7 +1965,8 @@ template <int N> __device__ __forceinline__ void vm_wait6()
 }
 
 // ABL: diagnostic switches compiled in (SBLAS_ABLATE: 0x10000 no LDS reads / FMAs, 0x20000 no tile DMA, 0x40000 no
-// per-tile barrier; wrong results)
+// per-tile barrier, 0x40000000 no tile loop at all -- the fixed cost per panel: 48 us of 300 on the bench matrix;
+// wrong results)
 template <int G, bool ABL>
 __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
@@ -1991,7 +1992,7 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     const int row0 = panel * panel_rows;
     const int col0 = blockIdx.y * 64;
     const unsigned ld32 = (unsigned)ldbt;
-    const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
+    const int t_lo = span.x / W2_ROWS, t_hi = (ABL && (ablate & 0x40000000)) ? t_lo - 1 : span.y / W2_ROWS;
     // waves 12-15 load the tiles, waves 0-11 consume (a wave that did both had its window loads retire behind its own
     // tile fetches -- vmcnt is in order -- and the kernel ran twice as long)
     const bool loader = wave >= 12;
@@ -2175,6 +2176,8 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     __syncthreads(); // F
     const int nrows = min(panel_rows, rows - row0);
     const int ncols = min(64, n - col0);
+    // (fetching the old C values in the prologue, to take their HBM latency out of the epilogue, did not pay: the
+    //  registers they hold across the tile loop spill)
     for (int idx = tid; idx < 64 * panel_rows; idx += 1024) {
         const int r = idx % panel_rows, j = idx / panel_rows;
         if (r < nrows && j < ncols) {
