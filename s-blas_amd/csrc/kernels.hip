@@ -2034,6 +2034,9 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
         }
     };
 
+    // the first tile does not depend on the row pointers: fetch it while they are on their way
+    if (loader) dma_part(t_lo, 0, 0, 16);
+
     const int k = lane & 15, q = lane >> 4;
     // per-lane row state, relative to the first nonzero of the wave's rows (base of the two descriptors)
     const int wrow = min(row0 + wave * RW, rows);
@@ -2054,7 +2057,6 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     unsigned long long viol = 0ull; // lanes whose entry broke the "entries of a tile = window prefix" expectation
     int wca[G], wcb[G];
     double wva[G], wvb[G];
-    if (loader) dma_part(t_lo, 0, 0, 16);
 #pragma unroll
     for (int g = 0; g < G; ++g) window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
     // everything lands before the loop starts, so its counted waits (written for the steady state) hold from the
