@@ -594,11 +594,16 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         const bool tail = exclude_tail && rowptr[min((p + 1) * panel_rows, rows)] == rowptr[rows];
         const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len && !tail &&
                         (float)nnz >= min_density * (float)(last - first + 1);
-        info[p] = ok ? make_int2(first, last) : make_int2(1, 0);
-        // widest column span of any panel (slot after the verdicts, zeroed by the launcher): the direct kernel picks
-        // its panel -> XCD map from it
-        if (last >= first) atomicMax(&info[npanels].x, last - first + 1);
+        // windowed: (first, last).  Direct: x > y, and for a non-empty panel the span stays recoverable
+        // (first = -1 - x, last = -2 - y): the direct kernel samples three panels to choose its panel -> XCD map
+        info[p] = ok ? make_int2(first, last) : (last >= first ? make_int2(-1 - first, -2 - last) : make_int2(1, 0));
     }
+}
+// column span of a classified panel (0 for an empty one)
+__device__ __forceinline__ int panel_span(int2 v)
+{
+    if (v.x >= 0) return v.y >= v.x ? v.y - v.x + 1 : 0;
+    return (-2 - v.y) - (-1 - v.x) + 1;
 }
 
 template <int CH>
@@ -2241,11 +2246,12 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
     // bands: the band must fit the Infinity Cache once, not once per XCD); otherwise one contiguous range per XCD
-    // (`interleave` < 0: decide from the widest panel span the classifier recorded -- a band of B rows wider than 16 MB)
+    // (`interleave` < 0: decide from the column spans the classifier recorded -- a band of B rows wider than 16 MB)
     if (interleave < 0) {
         interleave = 0;
-        if (info != nullptr) {
-            const int widest = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+        if (info != nullptr) { // every workgroup samples the same three panels, so they all agree
+            const int np_info = (rows + info_panel_rows - 1) / info_panel_rows;
+            const int widest = max(panel_span(info[0]), max(panel_span(info[np_info / 2]), panel_span(info[np_info - 1])));
             interleave = (long long)widest * (HALF ? 512 : 1024) > (16ll << 20);
         }
     }
@@ -2961,7 +2967,6 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
-                (void)hipMemsetAsync(winfo + np, 0, sizeof(int2), s);
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
                                    np, info_rows, rowptr, colidx, (gen4 || gen5 || gen6) ? 0x7fffffff : ch * 64,
                                    /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
