@@ -1,11 +1,23 @@
 // kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the S-BLAS CSR hot path.
 //
-//   dense_to_rowmajor_kernel   B (col-major) -> Bt (row-major, zero padded)          [stage 1 of SpMM]
-//   spmm_rowpanel_kernel       C = alpha*A*Bt + beta*C, one 32-row panel per workgroup [stage 2]
-//   spmm_rowpanel_narrow_kernel  same for n <= 32 (sub-wave lane groups)
-//   spmv_csr_kernel            y = alpha*A*x + beta*y, LPR lanes per row + in-wave reduction
-//   axpby_kernel               y = beta*y + alpha*x
-//   sum_replicas_kernel        in-place sum over g buffers that live on ONE device
+// SpMM  C = alpha*A*B + beta*C   (stage 1 + stage 2; the launcher at the end of this file picks the kernels)
+//   dense_to_rowmajor_kernel     B (col-major) -> Bt (row-major, zero padded, one all-zero row)          [stage 1]
+//   classify_panels_kernel       per row panel: dense enough over its column span for the LDS-tiled kernel?
+//   spmm_window6_kernel<G>       DEFAULT for qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA
+//                                loader waves), one DPP row per matrix row, streaming windows of A (generation 6)
+//   spmm_direct_dpp_kernel<HALF> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
+//   spmm_rowpanel_narrow_kernel  n <= 32 (sub-wave lane groups)
+//   spmm_window{,2,3,4,5}_kernel, spmm_rowpanel_kernel   earlier generations, selectable (SBLAS_SPMM_VARIANT) and
+//                                kept as regression cases of the parity suite
+// SpMV  y = alpha*A*x + beta*y
+//   spmv_csr_lds_kernel<RW,S>    DEFAULT above 96 nonzeros per row: x window of a 16-row block in LDS
+//   spmv_csr_seg_kernel<R,S>     DEFAULT for 33..96 per row: R rows per wave, segmented reduction
+//   spmv_csr_kernel<LPR>         DEFAULT up to 32 per row: LPR lanes per row, xor-shuffle fold
+//   spmv_csr_{burst,window,flat}_kernel   experiments (SBLAS_SPMV_VARIANT)
+// Epilogues and merges
+//   axpby_kernel                 y = beta*y + alpha*x                                        (kernel.h:27-38)
+//   merge_rowblocks_kernel       method-2 / SpMV merge: scatter packed row blocks, apply alpha / beta
+//   sum_replicas_kernel          in-place sum over g buffers that live on ONE device (folded ranks)
 //
 // These replace the closed-source cuSPARSE calls of the reference (spmm.h:146-149, :248-251;
 // spmv.h:104-106) and its one utility kernel (kernel.h:27-38).  Everything is written for
