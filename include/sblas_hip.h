@@ -83,6 +83,12 @@ int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
 /* Diagnostics: per-phase shader-cycle sums written by the windowed kernel when SBLAS_ABLATE has bit 2 set
  * (a diagnostic mode; see g_prof in kernels.hip for the slots). */
 int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset);
+/* Diagnostics for per-kernel timing (bench.py's roofline object): while enabled, the SpMM launcher brackets the
+ * dominant stage-2 kernel (the LDS-windowed one, or the direct one when that variant is forced) with two HIP events
+ * on the launch stream; ..._last_kernel_ms waits for the second event of the most recent launch on the current device
+ * and returns the elapsed time.  Off by default: a timed region is not perturbed. */
+int sblas_hip_debug_spmm_kernel_events(int enable);
+int sblas_hip_debug_spmm_last_kernel_ms(float *ms);
 
 /* ---------------------------------------------------------------------------------------
  * SpMV:  y = alpha * A * x + beta * y

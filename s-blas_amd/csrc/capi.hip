@@ -201,6 +201,18 @@ int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset)
     return SBLAS_OK;
 }
 
+int sblas_hip_debug_spmm_kernel_events(int enable)
+{
+    sblas::kernel_events_enable(enable != 0);
+    return SBLAS_OK;
+}
+
+int sblas_hip_debug_spmm_last_kernel_ms(float *ms)
+{
+    if (!ms) return SBLAS_E_INVALID;
+    return sblas::kernel_events_last_ms(ms) == hipSuccess ? SBLAS_OK : SBLAS_E_HIP;
+}
+
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset)
 {
     if (!out) return SBLAS_E_INVALID;

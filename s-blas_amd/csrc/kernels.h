@@ -28,6 +28,8 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
                        const double *val, const double *x, double alpha, double beta, double *y);
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y);
 hipError_t launch_sum_replicas(hipStream_t s, const ReplicaPtrs &bufs, int g, int64_t n);
+void kernel_events_enable(bool on);
+hipError_t kernel_events_last_ms(float *ms);
 hipError_t launch_merge_rowblocks(hipStream_t s, int64_t M, int64_t N, int g, const double *const *src,
                                   const int64_t *start, const int64_t *nrows, double alpha, double beta, double *C,
                                   int64_t ldc);

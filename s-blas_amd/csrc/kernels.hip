@@ -2924,6 +2924,33 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
     return hipGetLastError();
 }
 
+// Diagnostics: two events around the dominant stage-2 kernel of the most recent launch on a device (see
+// sblas_hip_debug_spmm_kernel_events).
+namespace {
+bool g_kernel_events = false;
+struct KernelEvents {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool recorded = false;
+} g_kev[16];
+KernelEvents *kernel_events_slot()
+{
+    int dev = 0;
+    if (!g_kernel_events || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    KernelEvents &e = g_kev[dev];
+    if (!e.a && (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess)) return nullptr;
+    return &e;
+}
+} // namespace
+void kernel_events_enable(bool on) { g_kernel_events = on; }
+hipError_t kernel_events_last_ms(float *ms)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || !g_kev[dev].recorded) return hipErrorNotReady;
+    hipError_t e = hipEventSynchronize(g_kev[dev].b);
+    if (e != hipSuccess) return e;
+    return hipEventElapsedTime(ms, g_kev[dev].a, g_kev[dev].b);
+}
+
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
                                 double beta, double *C, int64_t ldc, int variant)
@@ -2995,6 +3022,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL(KERNEL<CHV>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr, colidx, val, Bt, \
                            ldbt, n, alpha, beta, C, ldc, winfo, ablate);                                             \
     } while (0)
+                KernelEvents *kev = kernel_events_slot();
+                if (kev) (void)hipEventRecord(kev->a, s);
                 if (gen6) {
 #define SBLAS_W6_LAUNCH(GV, ABLV, ABLARG)                                                                             \
     do {                                                                                                             \
@@ -3049,6 +3078,10 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                     else SBLAS_W_LAUNCH(spmm_window3_kernel, 7);
                 }
 #undef SBLAS_W_LAUNCH
+                if (kev) {
+                    (void)hipEventRecord(kev->b, s);
+                    kev->recorded = true;
+                }
                 info = winfo;
             }
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;

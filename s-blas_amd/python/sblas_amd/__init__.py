@@ -18,7 +18,8 @@ EXPORTS = [
     "sblas_hip_version", "sblas_hip_error_string", "sblas_hip_device_count",
     "sblas_hip_spmm_csr_f64_i32_workspace", "sblas_hip_spmm_csr_f64_i32", "sblas_hip_spmm_ldbt",
     "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
-    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_spmm_cycle_stamps", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
+    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_spmm_cycle_stamps",
+    "sblas_hip_debug_spmm_kernel_events", "sblas_hip_debug_spmm_last_kernel_ms", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
     "sblas_hip_merge_rowblocks_f64", "sblas_hip_merge_rowblocks_local_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
@@ -64,6 +65,10 @@ def lib():
     L.sblas_hip_debug_spmm_cycle_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.sblas_hip_debug_spmm_panel_stats.restype = C.c_int
     L.sblas_hip_debug_spmm_panel_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.sblas_hip_debug_spmm_kernel_events.restype = C.c_int
+    L.sblas_hip_debug_spmm_kernel_events.argtypes = [C.c_int]
+    L.sblas_hip_debug_spmm_last_kernel_ms.restype = C.c_int
+    L.sblas_hip_debug_spmm_last_kernel_ms.argtypes = [C.POINTER(C.c_float)]
     L.sblas_hip_spmv_csr_f64_i32.restype = C.c_int
     L.sblas_hip_spmv_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, f64, f64, vp]
     L.sblas_hip_axpby_f64.restype = C.c_int
@@ -201,6 +206,17 @@ def panel_stats(reset=True):
     out = (C.c_uint64 * 4)()
     check(lib().sblas_hip_debug_spmm_panel_stats(out, 1 if reset else 0), "sblas_hip_debug_spmm_panel_stats")
     return int(out[0]), int(out[1]), int(out[2])
+
+
+def kernel_events(enable):
+    check(lib().sblas_hip_debug_spmm_kernel_events(1 if enable else 0), "sblas_hip_debug_spmm_kernel_events")
+
+
+def last_kernel_ms():
+    """Duration of the dominant stage-2 kernel of the most recent SpMM launch (waits for it); needs kernel_events(True)."""
+    ms = C.c_float()
+    check(lib().sblas_hip_debug_spmm_last_kernel_ms(C.byref(ms)), "sblas_hip_debug_spmm_last_kernel_ms")
+    return float(ms.value)
 
 
 def cycle_stamps(reset=True):
