@@ -609,6 +609,9 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         // windowed: (first, last).  Direct: x > y, and for a non-empty panel the span stays recoverable
         // (first = -1 - x, last = -2 - y): the direct kernel samples three panels to choose its panel -> XCD map
         info[p] = ok ? make_int2(first, last) : (last >= first ? make_int2(-1 - first, -2 - last) : make_int2(1, 0));
+        // the middle panel's column span, copied to the slot after the verdicts (one writer): the direct kernel takes
+        // it as the band width of the matrix when it chooses its panel -> XCD map
+        if (p == npanels / 2) info[npanels] = make_int2(last >= first ? last - first + 1 : 0, 0);
     }
 }
 // column span of a classified panel (0 for an empty one)
@@ -2258,13 +2261,12 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
     // bands: the band must fit the Infinity Cache once, not once per XCD); otherwise one contiguous range per XCD
-    // (`interleave` < 0: decide from the column spans the classifier recorded -- a band of B rows wider than 16 MB)
+    // (`interleave` < 0: decide from the column span the classifier recorded -- a band of B rows wider than 16 MB)
     if (interleave < 0) {
         interleave = 0;
-        if (info != nullptr) { // every workgroup samples the same three panels, so they all agree
-            const int np_info = (rows + info_panel_rows - 1) / info_panel_rows;
-            const int widest = max(panel_span(info[0]), max(panel_span(info[np_info / 2]), panel_span(info[np_info - 1])));
-            interleave = (long long)widest * (HALF ? 512 : 1024) > (16ll << 20);
+        if (info != nullptr) { // one value for every workgroup: the middle panel's span, left by the classifier
+            const int band = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+            interleave = (long long)band * (HALF ? 512 : 1024) > (16ll << 20);
         }
     }
     // (a persistent form -- a few workgroups per CU walking the panels, two scalar loads per skipped panel -- was tried
