@@ -2027,15 +2027,15 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[g][j] = 0.0;
 
-    // ---- tile DMA (as in the fifth generation): wave w moves Bt rows 8w..8w+7 of a tile
+    // ---- tile DMA: loader wave lw (= wave - 12) moves Bt rows 32 lw .. 32 lw + 31 of a tile: 16 instructions of two
+    // rows each (lanes 0-31 the first, lanes 32-63 the second); tile row j lives at LDS byte j * 512.  Rows past the end
+    // of B are clamped to row `cols`, the all-zero row of the workspace (scalar addresses when all 32 rows exist)
     const unsigned ldb8 = ld32 * 8u;
     const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
     const unsigned pair_off = (unsigned)(lane >> 5) * ldb8 + piece_off;
     const char *bt_bytes = reinterpret_cast<const char *>(Bt);
     int dummy = 0;
-    // instructions i0 .. i1-1 of the wave's share (four in all); issued in two or three instalments per tile: with all
-    // four at the top of a tile the kernel ran twice as long (SBLAS_ABLATE experiments: half the volume cost nothing,
-    // the full volume 150 us whatever the source or the destination)
+    // instructions i0 .. i1-1 of the wave's share
     auto dma_part = [&](int t, int buf, int i0, int i1) {
         const int lw = wave - 12;
         const int r0 = t * W2_ROWS + lw * 32;
@@ -3009,7 +3009,9 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
-                                   np, info_rows, rowptr, colidx, (gen4 || gen5 || gen6) ? 0x7fffffff : ch * 64,
+                                   np, info_rows, rowptr, colidx,
+                                   /* generation 6 addresses a wave's 8-12 rows through 32-bit buffer offsets */
+                                   gen6 ? (1 << 24) : (gen4 || gen5) ? 0x7fffffff : ch * 64,
                                    /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
                                       direct kernel, so ask for 8 per row and 128-column tile on average */
                                    (gen4 || gen5 || gen6) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0);
