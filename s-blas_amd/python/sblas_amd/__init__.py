@@ -11,7 +11,8 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.normpath(os.path.join(_PKG, "..", ".."))
-LIB_PATH = os.path.join(_ROOT, "lib", "libsblas_hip.so")
+# SBLAS_LIB_PATH: A/B runs of two builds of the library (experiments only)
+LIB_PATH = os.environ.get("SBLAS_LIB_PATH") or os.path.join(_ROOT, "lib", "libsblas_hip.so")
 
 # every symbol include/sblas_hip.h declares (tests check that the .so exports all of them)
 EXPORTS = [
