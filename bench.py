@@ -274,7 +274,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     t_stage1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
-    t_stage2 = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    s2 = [e[1].elapsed_time(e[2]) for e in ev]
+    t_stage2 = float(np.mean(s2)) * 1e-3
 
     # correctness guard on this rank's result: C = 1 + (warmup+steps) * A*B on 64 sampled rows vs the oracle
     total_steps = args.warmup + args.steps
@@ -328,7 +329,8 @@ def main():
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_roof * 1e3, 5),
                      "kernel_ms_source": "HIP events around the one launch, 10 steps" if t_dom else "HIP events around stage 2",
-                     "stage2_ms": round(t_stage2 * 1e3, 5),
+                     "stage2_ms": round(t_stage2 * 1e3, 5), "stage2_ms_median": round(float(np.median(s2)), 5),
+                     "stage2_ms_min": round(float(np.min(s2)), 5),
                      "staging_kernel_ms": round(t_stage1 * 1e3, 5),
                      "kernel_gflops": round(flops_step / t_roof / 1e9, 1)},
         "hbm_gbs_whole_step": round(alg / (elapsed / args.steps) / 1e9, 1),
