@@ -2588,9 +2588,21 @@ __global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, 
     }
     lo = max(lo, 0);
     hi = min(hi, cols - 1);
-    // a span that does not fit is not staged at all: every gather then goes to global memory, as in the plain kernel
+    // a span that does not fit is not staged at all: every gather then goes to global memory, as in the plain kernel.
+    // The window starts at an even column so that it can be fetched by LDS-DMA in 16-byte pieces (x 16-byte aligned,
+    // the last pair inside x); otherwise eight bytes per thread through registers.
+    lo &= ~1;
     const int wlen = (hi - lo + 1 <= SPMV_LDS_CAP) ? hi - lo + 1 : 0;
-    if (wlen > 0) {
+    const int pairs = (wlen + 1) >> 1;
+    if (wlen > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && lo + 2 * pairs <= cols) {
+        const char *src = reinterpret_cast<const char *>(x + lo);
+        for (int p0 = wave * 64; p0 < pairs; p0 += 1024) { // (wave-uniform trip count)
+            const int pr = min(p0 + lane, pairs - 1);  // clamped lanes rewrite the last pair into the slack area
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)pr * 16),
+                                             (__attribute__((address_space(3))) void *)(xs + 2 * p0), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (wlen > 0) {
         // the whole window in one burst of loads (clamped indices), then the stores
         constexpr int PASSES = SPMV_LDS_CAP / 1024;
         double t[PASSES];
@@ -2926,6 +2938,20 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
     return hipGetLastError();
 }
 
+// compute units of the current device (queried once per device)
+static int compute_units()
+{
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (cached[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // Diagnostics: two events around the dominant stage-2 kernel of the most recent launch on a device (see
 // sblas_hip_debug_spmm_kernel_events).
 namespace {
@@ -2975,11 +3001,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 if (gen6) {
                     // one workgroup per CU at a time: pick the groups per wave (2 or 3) and the panel height (a
                     // multiple of the rows of a wave) that minimise rounds x (height + per-tile fixed cost)
-                    int ncu = 256;
-                    int dev = 0;
-                    if (hipGetDevice(&dev) == hipSuccess)
-                        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-                    if (ncu < 1) ncu = 1;
+                    const int ncu = compute_units();
                     int best = 128;
                     long best_cost = -1;
                     for (int g = 2; g <= W6_GMAX; ++g)
@@ -3196,10 +3218,10 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
 #define SBLAS_SPMV_LDS(RWV, SV)                                                                                      \
     do {                                                                                                             \
         (void)hipFuncSetAttribute((const void *)spmv_csr_lds_kernel<RWV, SV>,                                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SPMV_LDS_CAP * sizeof(double))); \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SPMV_LDS_CAP + 128) * sizeof(double))); \
         hipLaunchKernelGGL((spmv_csr_lds_kernel<RWV, SV>),                                                           \
                            dim3((unsigned)((rows + SPMV_LDS_ROWS * RWV - 1) / (SPMV_LDS_ROWS * RWV))), dim3(1024),    \
-                           SPMV_LDS_CAP * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha, beta, y);    \
+                           (SPMV_LDS_CAP + 128) * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha, beta, y); \
         return hipGetLastError();                                                                                    \
     } while (0)
     // long rows: x window in LDS (bench matrix: 70-73 us vs 82-85 us for the lanes-per-row kernel); a block whose

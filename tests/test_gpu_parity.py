@@ -595,6 +595,30 @@ def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
         assert close(y.cpu().numpy(), ref), (kind, alpha, beta)
 
 
+@pytest.mark.parametrize("xoff", [0, 1])
+@pytest.mark.parametrize("K", [4000, 4001])
+def test_spmv_lds_window_fetch_paths(env, xoff, K):
+    """The long-row kernel fetches the x window by LDS-DMA in 16-byte pieces when x is 16-byte aligned and the last
+    pair lies inside x, otherwise through registers: an x that starts 8 bytes off, an odd column count with rows
+    that reach the last column, and the aligned case."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    M = 3000
+    rp, ci, v = synth.banded(M, 200, 900)
+    ci = np.minimum(ci.astype(np.int64) + (K - M), K - 1).astype(np.int32)     # push the band against the last column
+    for r in range(M):                                                         # (clipping made duplicates: fine, keep order)
+        ci[rp[r]:rp[r + 1]].sort()
+    A = Dev(torch, dev, rp, ci, v, K)
+    rng = np.random.default_rng(K + xoff)
+    xh, yh = rng.standard_normal(K), rng.standard_normal(M)
+    xbuf = torch.zeros(K + 2, dtype=torch.float64, device=dev)
+    x = xbuf[xoff:xoff + K]
+    x.copy_(torch.from_numpy(xh))
+    y = torch.from_numpy(yh.copy()).to(dev)
+    sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, 1.5, -1.0, y)
+    assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), 1.5, -1.0))
+
+
 @pytest.mark.parametrize("variant", ["seg2", "seg3", "seg4", "seg8"])
 @pytest.mark.parametrize("avg", [2, 30, 73, 150])
 def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
