@@ -42,7 +42,7 @@ def measured_traffic(kernel, rows, nnz, n):
     WRITE_SIZE in separate passes, gfx950 read correction applied there).  PMC counters cannot be read from inside
     this process, so the figure is only reported when the profile was taken on this very kernel and workload."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic*.json")), reverse=True):
         try:
             d = json.load(open(path))
             w = d.get("workload", {})
@@ -169,17 +169,21 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
         want = 1.0 + (args.warmup + args.steps) * rs
         if not np.allclose(y.cpu().numpy(), want, rtol=1e-9, atol=1e-9):
             raise SystemExit("spmv bench result mismatch")
+        sp_kernel = ("spmv_csr_lds_kernel" if nnz > 96 * rows and os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto", "lds")
+                     else "spmv_csr_kernel")
+        sp_traffic, sp_src = (measured_traffic(sp_kernel, rows, nnz, 1)
+                              if os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto") else (None, None))
         out = {"metric": "SpMV GFLOP/s (2*nnz/t), CSR fp64", "value": round(world * 2.0 * nnz * args.steps / elapsed / 1e9, 2),
                "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
                "config": {"workload": "SpMV y=A*x+y, %s, nnz=%d, replicas only" % (name, nnz), "rows": rows, "nnz": nnz},
                "roofline": {"bound": "hbm",
-                            "kernel": ("spmv_csr_lds_kernel" if nnz > 96 * rows and os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto", "lds")
-                                       else "spmv_csr_kernel"),
+                            "kernel": sp_kernel,
                             "achieved": round(alg / t_k / 1e9, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t_k / 1e9 / HBM_PEAK_GBS, 4),
-                            "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": round(t_k * 1e3, 5)},
+                            "traffic": sp_traffic, "traffic_source": sp_src, "algorithmic_bytes_per_launch": alg,
+                            "kernel_ms": round(t_k * 1e3, 5)},
                "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -19,24 +19,36 @@ for name in ("bench_default", "bench_spmv"):
 
 CORR = ("gfx950: FETCH_SIZE counts 64 B per 128 B request -> read bytes = 2*FETCH_SIZE (MI355X_MICROARCH.md, HBM); "
         "WRITE_SIZE exact; unit KiB")
-per = collections.defaultdict(dict)
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in sorted(glob.glob(f"{src}/pmc_{c}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)[:1]:
-        agg = collections.defaultdict(list)
-        for row in csv.DictReader(open(f)):
-            if row["Counter_Name"] == c:
-                agg[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
-        for k, v in agg.items():
-            per[k][c] = sum(v) / len(v)
-path = f"{dst}/{rnd}_hbm_traffic.json"
-doc = json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
-doc["command"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 "
-                  "--warmup 1 --cpu-seconds 0")
-for k, v in per.items():
-    if "sblas::" not in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
-        continue
-    doc["kernels"][k] = {"FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
-                         "hbm_bytes_per_launch_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
-                         "correction": CORR}
-    print("traffic", k, doc["kernels"][k]["hbm_bytes_per_launch_corrected"])
-json.dump(doc, open(path, "w"), indent=1)
+
+
+def merge(prefix, path, command, workload):
+    per = collections.defaultdict(dict)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in sorted(glob.glob(f"{src}/{prefix}_{c}/*/*counter_collection.csv"), key=os.path.getmtime, reverse=True)[:1]:
+            agg = collections.defaultdict(list)
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == c:
+                    agg[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
+            for k, v in agg.items():
+                per[k][c] = sum(v) / len(v)
+    if not per:
+        return
+    doc = json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
+    doc["command"] = command
+    doc.setdefault("workload", workload)
+    for k, v in per.items():
+        if "sblas::" not in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        doc["kernels"][k] = {"FETCH_SIZE_KB_per_launch": v["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch": v["WRITE_SIZE"],
+                             "hbm_bytes_per_launch_corrected": int((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024),
+                             "correction": CORR}
+        print("traffic", k, doc["kernels"][k]["hbm_bytes_per_launch_corrected"])
+    json.dump(doc, open(path, "w"), indent=1)
+
+
+merge("pmc", f"{dst}/{rnd}_hbm_traffic.json",
+      "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0",
+      {"rows": 72000, "nnz": 28728000, "n": 64})
+merge("pmcspmv", f"{dst}/{rnd}_hbm_traffic_spmv.json",
+      "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --op spmv --steps 5 --warmup 1",
+      {"rows": 72000, "nnz": 28728000, "n": 1})

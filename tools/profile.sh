@@ -13,5 +13,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /dev/null 2> $OUT/pmc_$c.err
   echo "$c rc=$?"
 done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcspmv_$c -- python3 $R/bench.py --op spmv --steps 5 --warmup 1 > /dev/null 2> $OUT/pmcspmv_$c.err
+  echo "spmv $c rc=$?"
+done
 cd $R && python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"; cat $OUT/bench_default.json
 python bench.py --op spmv --steps 100 > $OUT/bench_spmv.json 2>/dev/null; cat $OUT/bench_spmv.json
