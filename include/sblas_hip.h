@@ -63,9 +63,11 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream,
 
 /* The two stages of the call above, exposed so that a caller that multiplies the same B more
  * than once (method 2 keeps B resident) or wants per-stage timing can drive them itself:
- *   stage 1: Bt (cols x ldbt row-major, zero padded) <- B (cols x n col-major)
- *   stage 2: the row-panel SpMM kernel reading Bt.
- * ldbt = sblas_hip_spmm_ldbt(n). */
+ *   stage 1: Bt ((cols + 1) x ldbt row-major, zero padded, last row all zero) <- B (cols x n col-major)
+ *   stage 2: the row-panel SpMM kernels reading Bt.
+ * ldbt = sblas_hip_spmm_ldbt(n).  Bt must be a buffer of sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n)
+ * bytes: stage 2 keeps its panel verdicts behind the staging copy.  (The split form does not chunk columns:
+ * (cols + 1) * ldbt * 8 must stay below 4 GiB; the one-call form walks wider B in column chunks.) */
 int64_t sblas_hip_spmm_ldbt(int64_t n);
 int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n,
                                     const double *B, int64_t ldb, double *Bt, int64_t ldbt);
@@ -84,7 +86,7 @@ int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
  * (a diagnostic mode; see g_prof in kernels.hip for the slots). */
 int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset);
 /* Diagnostics for per-kernel timing (bench.py's roofline object): while enabled, the SpMM launcher brackets the
- * dominant stage-2 kernel (the LDS-windowed one, or the direct one when that variant is forced) with two HIP events
+ * dominant stage-2 kernel (the LDS-windowed one) with two HIP events
  * on the launch stream; ..._last_kernel_ms waits for the second event of the most recent launch on the current device
  * and returns the elapsed time.  Off by default: a timed region is not perturbed. */
 int sblas_hip_debug_spmm_kernel_events(int enable);
