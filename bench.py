@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 # stage-2 kernel launched for a 64-column block under each SBLAS_SPMM_VARIANT (s-blas_amd/csrc/kernels.hip)
 KERNEL_OF_VARIANT = {"": "spmm_window6_kernel", "auto": "spmm_window6_kernel", "win6": "spmm_window6_kernel", "win5": "spmm_window5_kernel<false>", "win3": "spmm_window3_kernel<7>",
                      "win2": "spmm_window2_kernel<7>", "win4": "spmm_window4_kernel<false>",
-                     "dpp": "spmm_direct_dpp_kernel<true>", "direct": "spmm_rowpanel_kernel",
+                     "dpp": "spmm_direct_dpp_kernel<2>", "direct": "spmm_rowpanel_kernel",
                      "win32": "spmm_window_kernel<2,64,8>", "win64": "spmm_window_kernel<4,128,4>",
                      "win128": "spmm_window_kernel<8,128,4>", "win64w64": "spmm_window_kernel<4,64,8>",
                      "win32w128": "spmm_window_kernel<2,128,4>"}
@@ -315,7 +315,7 @@ def main():
     flops_step = 2.0 * nnz * n                      # per GPU
     value = world * flops_step * args.steps / elapsed / 1e9
     alg = algorithmic_bytes(rows, cols, nnz, n, True)
-    kernel = KERNEL_OF_VARIANT.get(os.environ.get("SBLAS_SPMM_VARIANT", ""), "spmm_direct_dpp_kernel<true>") if n > 32 and n <= 64 else "spmm (n=%d)" % n
+    kernel = KERNEL_OF_VARIANT.get(os.environ.get("SBLAS_SPMM_VARIANT", ""), "spmm_direct_dpp_kernel<2>") if n > 32 and n <= 64 else "spmm (n=%d)" % n
     # (the committed PMC passes were taken with the default kernel selection only)
     traffic, traffic_src = (measured_traffic(kernel, rows, nnz, n)
                             if os.environ.get("SBLAS_SPMM_VARIANT", "") in ("", "auto", "win6") else (None, None))

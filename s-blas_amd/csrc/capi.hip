@@ -87,15 +87,29 @@ int sblas_hip_device_count(void)
     return n;
 }
 
-int64_t sblas_hip_spmm_ldbt(int64_t n)
+// narrow = true: the 16- / 32-column tiers (64-bit addressing, the last resort when even a 64-column staging copy
+// would exceed the 32-bit offset window, and what SBLAS_SPMM_MIN_LDBT=0 selects)
+static int64_t ldbt_pick(int64_t n, bool narrow)
 {
     if (n <= 0) return 0;
     if (n <= 8) return 8;
-    if (n <= 16) return 16;
-    if (n <= 32) return 32;
+    if (n <= 16 && narrow) return 16;
+    if (n <= 32 && narrow) return 32;
     if (n <= 64) return 64;
     return (n + 127) / 128 * 128; // wide tiles are 128 columns (two per lane)
 }
+
+int64_t sblas_hip_spmm_ldbt(int64_t n)
+{
+    // 9..32 columns run on the 64-column staging copy: row panels that qualify for the LDS-tiled kernel are 2-3x faster
+    // there than in the narrow kernels (banded bench matrix, N = 16 / 32: 0.31 / 0.33 ms against 0.58 / 1.05 ms) and the
+    // direct kernel reads only the first 32 columns of a Bt row (four nonzeros per instruction; Queen-like rows,
+    // N = 16 / 32: 0.45 / 0.46 ms against 0.42 / 0.78 ms).  SBLAS_SPMM_MIN_LDBT=0 restores the 16- and 32-column
+    // kernels (tests, A/B runs).
+    const char *me = getenv("SBLAS_SPMM_MIN_LDBT");
+    return ldbt_pick(n, me && atoi(me) < 64);
+}
+static bool ldbt_ok(int64_t ldbt, int64_t n) { return ldbt == ldbt_pick(n, false) || ldbt == ldbt_pick(n, true); }
 
 // The kernels address Bt with 32-bit byte offsets, so one stage-2 launch can cover at most 4 GiB of Bt.  The
 // top-level call therefore walks the dense columns in chunks of `w` columns with (cols+1)*ldbt(w)*8 <= 4 GiB
@@ -120,6 +134,12 @@ static int64_t spmm_chunk_cols(int64_t cols, int64_t n)
     if (row_bytes * 64ull <= lim) return 64;
     return 32; // the narrow kernels use 64-bit addressing: no limit
 }
+// ldbt of a chunk of nj columns: the narrow tier when the chunk width itself was forced down to 32
+static int64_t chunk_ldbt(int64_t cols, int64_t n, int64_t nj)
+{
+    const bool forced_narrow = spmm_chunk_cols(cols, n) <= 32 && 8ull * ((uint64_t)cols + 1) * 64ull > bt_byte_limit();
+    return forced_narrow ? ldbt_pick(nj, true) : sblas_hip_spmm_ldbt(nj);
+}
 
 size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
 {
@@ -128,7 +148,7 @@ size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t 
     // Bt for one column chunk plus one extra all-zero row (the target of masked DPP slots), then one int2 per
     // row panel (the panel classifier's verdicts)
     const int64_t w = spmm_chunk_cols(cols, n);
-    const size_t bt = ((size_t)cols + 1) * (size_t)sblas_hip_spmm_ldbt(w) * sizeof(double);
+    const size_t bt = ((size_t)cols + 1) * (size_t)chunk_ldbt(cols, n, w) * sizeof(double);
     const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_MIN_PANEL_ROWS - 1) / sblas::SPMM_MIN_PANEL_ROWS;
     return bt + panels * 8 + 16; // + one spare entry and the widest-span slot read by the direct kernel
 }
@@ -138,7 +158,7 @@ int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t
 {
     if (cols < 0 || n < 0) return SBLAS_E_INVALID;
     if (cols == 0 || n == 0) return SBLAS_OK;
-    if (!B || !Bt || ldb < cols || ldbt < n || ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
+    if (!B || !Bt || ldb < cols || ldbt < n || !ldbt_ok(ldbt, n)) return SBLAS_E_INVALID;
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     return sblas::launch_dense_to_rowmajor((hipStream_t)stream, cols, n, B, ldb, Bt, ldbt) == hipSuccess
@@ -154,7 +174,7 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val) || n < 0) return SBLAS_E_INVALID;
     if (rows == 0 || n == 0) return SBLAS_OK;
     if (!C || ldc < rows || n > INT_MAX) return SBLAS_E_INVALID;
-    if (ldbt != sblas_hip_spmm_ldbt(n)) return SBLAS_E_INVALID;
+    if (!ldbt_ok(ldbt, n)) return SBLAS_E_INVALID;
     if (cols > 0 && !Bt) return SBLAS_E_INVALID;
     // the kernels address Bt with 32-bit element offsets (row * ldbt + column)
     if (ldbt >= 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_E_INVALID; // 32-bit byte offsets
@@ -182,7 +202,7 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     const int64_t w = spmm_chunk_cols(cols, n);
     for (int64_t j0 = 0; j0 < n; j0 += w) { // one pass unless Bt would exceed the 32-bit offset window
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
-        const int64_t ldbt = sblas_hip_spmm_ldbt(nj);
+        const int64_t ldbt = chunk_ldbt(cols, n, nj);
         int rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt);
         if (rc != SBLAS_OK) return rc;
         rc = sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, nj, alpha,

@@ -5,7 +5,7 @@
 //   classify_panels_kernel       per row panel: dense enough over its column span for the LDS-tiled kernel?
 //   spmm_window6_kernel<G>       DEFAULT for qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA
 //                                loader waves), one DPP row per matrix row, streaming windows of A (generation 6)
-//   spmm_direct_dpp_kernel<HALF> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
+//   spmm_direct_dpp_kernel<GROUPS> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
 //   spmm_rowpanel_narrow_kernel  n <= 32 (sub-wave lane groups)
 //   spmm_window{,2,3,4,5}_kernel, spmm_rowpanel_kernel   earlier generations, selectable (SBLAS_SPMM_VARIANT) and
 //                                kept as regression cases of the parity suite
@@ -2248,14 +2248,18 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
                  : [gv] "v"(gv), [x0] "v"(B0.x), [y0] "v"(B0.y), [x1] "v"(B1.x), [y1] "v"(B1.y), [x2] "v"(B2.x),    \
                    [y2] "v"(B2.y), [x3] "v"(B3.x), [y3] "v"(B3.y))
 
-template <bool HALF>
+// GROUPS = 1: 128-column tile, one nonzero per instruction; 2: 64 columns, two nonzeros; 4: 32 columns, four (one per
+// DPP row) -- n <= 32 runs on the 64-column staging copy and reads the first half of every Bt row
+template <int GROUPS>
 __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave)
 {
-    constexpr int TILE_COLS = HALF ? 64 : 128;
-    constexpr int PER_STEP = HALF ? 32 : 16; // nonzeros handled by one 16-slot sweep
+    static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "lane groups of 64, 32 or 16 lanes");
+    constexpr int TILE_COLS = 128 / GROUPS;
+    constexpr int PER_STEP = 16 * GROUPS; // nonzeros handled by one 16-slot sweep
+    constexpr int GLANES = 64 / GROUPS;   // lanes that share a nonzero
     __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
@@ -2266,7 +2270,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
         interleave = 0;
         if (info != nullptr) { // one value for every workgroup: the middle panel's span, left by the classifier
             const int band = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
-            interleave = (long long)band * (HALF ? 512 : 1024) > (16ll << 20);
+            interleave = (long long)band * (TILE_COLS * 8) > (16ll << 20);
         }
     }
     // (a persistent form -- a few workgroups per CU walking the panels, two scalar loads per skipped panel -- was tried
@@ -2282,9 +2286,9 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
         if (mine && lane == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
     }
     const int sub = lane & 15;
-    const int half = HALF ? (lane >> 5) : 0;
+    const int half = lane / GLANES; // which of the GROUPS nonzeros of a step this lane works on
     const unsigned ldb8 = (unsigned)ldbt * 8u;                                       // bytes per Bt row
-    const unsigned lb = (unsigned)(col0 * 8) + (unsigned)(HALF ? (lane & 31) : lane) * 16u; // this lane's 2 columns
+    const unsigned lb = (unsigned)(col0 * 8) + (unsigned)(lane % GLANES) * 16u; // this lane's 2 columns
     const unsigned zero_off = (unsigned)cols * ldb8;                                 // Bt[cols][*] == 0
     const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
 
@@ -2343,14 +2347,18 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
             }
         }
     }
-    if (HALF) { // the two halves summed different nonzeros of the same row
+    if (GROUPS == 4) { // the lane groups summed different nonzeros of the same row
+        acc0 += __shfl_xor(acc0, 16, WAVE);
+        acc1 += __shfl_xor(acc1, 16, WAVE);
+    }
+    if (GROUPS >= 2) {
         acc0 += __shfl_xor(acc0, 32, WAVE);
         acc1 += __shfl_xor(acc1, 32, WAVE);
     }
     __shared__ int row_mine[WIDE_PANEL];
     if (lane == 0) row_mine[wave] = mine ? 1 : 0;
-    if (!HALF || lane < 32) {
-        const int cl = 2 * (HALF ? (lane & 31) : lane);
+    if (lane < GLANES) {
+        const int cl = 2 * lane;
         ctile[cl][wave] = acc0;
         ctile[cl + 1][wave] = acc1;
     }
@@ -3117,15 +3125,20 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             const size_t pad = dl ? (size_t)atoi(dl) : (ldbt == 64 ? 0 : 90000);
             const char *dm = getenv("SBLAS_DIRECT_MAP"); /* experiments: interleave | contiguous; default: by span */
             const int interleave = (dm && !strcmp(dm, "interleave")) ? 1 : (dm && !strcmp(dm, "contiguous")) ? 0 : -1;
-            if (ldbt == 64) {
+            if (ldbt == 64 && n <= 32) {
                 dim3 grid((unsigned)wide_panels, 1u);
-                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-                hipLaunchKernelGGL(spmm_direct_dpp_kernel<true>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
+                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+            } else if (ldbt == 64) {
+                dim3 grid((unsigned)wide_panels, 1u);
+                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<2>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
                                    wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
             } else {
                 dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 128));
-                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
-                hipLaunchKernelGGL(spmm_direct_dpp_kernel<false>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
+                if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
                                    wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
             }
         } else if (variant == SPMM_VARIANT_DIRECT) {

@@ -122,6 +122,30 @@ def test_spmm_every_column_count(env, variant_env, variant, n):
         assert close(got, ref), (n, alpha, beta, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("n", [9, 16, 17, 31, 32])
+def test_spmm_narrow_kernels_still_correct(env, ash85, n):
+    """9..32 columns run on the 64-column kernels by default; SBLAS_SPMM_MIN_LDBT=0 selects the 16- / 32-column
+    kernels again (kept for A/B runs): both must match the oracle."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows = 700
+    rp, ci, v = synth.banded(rows, 40, 90)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(n)
+    B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 0.5, 2.0)
+    old = os.environ.get("SBLAS_SPMM_MIN_LDBT")
+    try:
+        for setting in ("0", "64"):
+            os.environ["SBLAS_SPMM_MIN_LDBT"] = setting
+            assert close(gpu_spmm(sblas, torch, dev, A, B, rows, n, 0.5, 2.0, C0, rows), ref), (n, setting)
+    finally:
+        if old is None:
+            os.environ.pop("SBLAS_SPMM_MIN_LDBT", None)
+        else:
+            os.environ["SBLAS_SPMM_MIN_LDBT"] = old
+
+
 @pytest.mark.parametrize("n", [8, 64, 96])
 def test_spmm_leading_dimensions_and_untouched_padding(env, n):
     """ldb > K and ldc > M (method 2 writes into Ccopy with ldc = M != m_i, spmm.h:224-231): the rows of C
