@@ -37,6 +37,7 @@ inline int spmm_variant()
     if (!e || !*e) return sblas::SPMM_VARIANT_AUTO;
     if (!strcmp(e, "direct")) return sblas::SPMM_VARIANT_DIRECT;
     if (!strcmp(e, "dpp")) return sblas::SPMM_VARIANT_DIRECT_DPP;
+    if (!strcmp(e, "rows")) return sblas::SPMM_VARIANT_DIRECT_ROWS;
     if (!strcmp(e, "win2")) return sblas::SPMM_VARIANT_WINDOW2;
     if (!strcmp(e, "win3")) return sblas::SPMM_VARIANT_WINDOW3;
     if (!strcmp(e, "win4")) return sblas::SPMM_VARIANT_WINDOW4;

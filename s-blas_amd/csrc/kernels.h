@@ -17,7 +17,7 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
 // row-panel x B-tile kernels (with their per-panel fallback) and the readlane kernel stay selectable for A/B runs
 // and tests through SBLAS_SPMM_VARIANT.
 enum { SPMM_VARIANT_AUTO = 0, SPMM_VARIANT_DIRECT = 1, SPMM_VARIANT_WINDOW_R32 = 2, SPMM_VARIANT_WINDOW_R64 = 3,
-       SPMM_VARIANT_WINDOW_R128 = 4, SPMM_VARIANT_WINDOW_R64W64 = 5, SPMM_VARIANT_WINDOW_R32W128 = 6, SPMM_VARIANT_DIRECT_DPP = 7, SPMM_VARIANT_WINDOW2 = 8, SPMM_VARIANT_WINDOW3 = 9, SPMM_VARIANT_WINDOW4 = 10, SPMM_VARIANT_WINDOW5 = 11, SPMM_VARIANT_WINDOW6 = 12 };
+       SPMM_VARIANT_WINDOW_R128 = 4, SPMM_VARIANT_WINDOW_R64W64 = 5, SPMM_VARIANT_WINDOW_R32W128 = 6, SPMM_VARIANT_DIRECT_DPP = 7, SPMM_VARIANT_WINDOW2 = 8, SPMM_VARIANT_WINDOW3 = 9, SPMM_VARIANT_WINDOW4 = 10, SPMM_VARIANT_WINDOW5 = 11, SPMM_VARIANT_WINDOW6 = 12, SPMM_VARIANT_DIRECT_ROWS = 13 };
 constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (one int2 of workspace per panel; generation 6: 32)
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,

@@ -6,7 +6,8 @@
 //   spmm_window6_kernel<G>       DEFAULT for qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA
 //                                loader waves), one DPP row per matrix row, streaming windows of A (generation 6)
 //   spmm_direct_dpp_kernel<GROUPS> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
-//   spmm_rowpanel_narrow_kernel  n <= 32 (sub-wave lane groups)
+//   spmm_direct_rows_kernel      direct panels of short-row matrices (< 32 per row): four rows per wave
+//   spmm_rowpanel_narrow_kernel  n <= 8 (sub-wave lane groups; 16 / 32 columns behind SBLAS_SPMM_MIN_LDBT=0)
 //   spmm_window{,2,3,4,5}_kernel, spmm_rowpanel_kernel   earlier generations, selectable (SBLAS_SPMM_VARIANT) and
 //                                kept as regression cases of the parity suite
 // SpMV  y = alpha*A*x + beta*y
@@ -2423,6 +2424,109 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2, direct form for SHORT rows: four matrix rows per wave, one per DPP row (the layout of the sixth windowed
+// generation, reading Bt from L2 instead of LDS).  With a row per wave a 5-nonzero row occupies a 16-slot sweep, a
+// 64-lane chunk load, a reduction and a C write of its own: 0.8 ms for a million such rows at N = 64 (17 % of the
+// HBM time).  Here lane k of DPP row q holds entry k of row 4w+q, step k serves the k-th nonzero of four rows at once,
+// a lane accumulates four columns of its row (two 16-byte loads per step), and a workgroup writes 64 rows of C.
+// Used for the direct panels when the matrix averages fewer than 32 nonzeros per row.
+// ---------------------------------------------------------------------------------------------
+constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
+__global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave)
+{
+    __shared__ double ctile[64][ROWS_PANEL + 1];
+    __shared__ int row_mine[ROWS_PANEL];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    const int k = lane & 15, q = lane >> 4;
+    const int col0 = blockIdx.y * 64;
+    if (col0 >= n) return; // a padding tile of ldbt (uniform over the workgroup)
+    if (interleave < 0) {
+        interleave = 0;
+        if (info != nullptr) {
+            const int band = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+            interleave = (long long)band * 512 > (16ll << 20);
+        }
+    }
+    const int row0 = (interleave ? (int)blockIdx.x : xcd_contiguous_panel(blockIdx.x, npanels)) * ROWS_PANEL;
+    const int rr = wave * 4 + q;
+    const int row = row0 + rr;
+    bool mine = row < rows;
+    if (info && mine) {
+        const int2 span = info[row / info_panel_rows];
+        mine = span.x > span.y;
+        if (mine && k == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
+    }
+    const unsigned ldb8 = (unsigned)ldbt * 8u;
+    const unsigned lb = (unsigned)(col0 * 8) + (unsigned)k * 16u; // columns 2k, 2k+1 (and 32+2k, 33+2k at +256 bytes)
+    const unsigned zero_off = (unsigned)cols * ldb8;
+    const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int p = 0, pend = 0;
+    if (mine) {
+        p = rowptr[row];
+        pend = rowptr[row + 1];
+    }
+    for (int base = p; __builtin_amdgcn_ballot_w64(base < pend) != 0ull; base += 16) {
+        const int idx = base + k;
+        const bool valid = idx < pend;
+        int c = 0;
+        double v = 0.0;
+        if (valid) {
+            c = colidx[idx];
+            v = val[idx];
+        }
+        const unsigned co = valid ? (unsigned)c * ldb8 : zero_off;
+        const double gv = valid ? v : 0.0;
+        const int left = min(16, max(pend - base, 0)); // the same in all 16 lanes of a DPP row
+        const int mx = max(max(__builtin_amdgcn_readlane(left, 0), __builtin_amdgcn_readlane(left, 16)),
+                           max(__builtin_amdgcn_readlane(left, 32), __builtin_amdgcn_readlane(left, 48)));
+#define SBLAS_LD(O) (*reinterpret_cast<const double2 *>(bt_bytes + (O)))
+#define SBLAS_ROWS_BLOCK(K0, K1, K2, K3)                                                                              \
+    {                                                                                                                \
+        unsigned o0, o1, o2, o3;                                                                                     \
+        SBLAS_DPP_OFF4(K0, K1, K2, K3, o0, o1, o2, o3);                                                              \
+        const double2 b0 = SBLAS_LD(o0), b1 = SBLAS_LD(o1), b2 = SBLAS_LD(o2), b3 = SBLAS_LD(o3);                    \
+        const double2 d0 = SBLAS_LD(o0 + 256u), d1 = SBLAS_LD(o1 + 256u), d2 = SBLAS_LD(o2 + 256u),                  \
+                      d3 = SBLAS_LD(o3 + 256u);                                                                      \
+        {                                                                                                            \
+            double &acc0 = a0, &acc1 = a1;                                                                           \
+            SBLAS_DPP_FMA4x2(K0, K1, K2, K3, b0, b1, b2, b3);                                                        \
+        }                                                                                                            \
+        {                                                                                                            \
+            double &acc0 = a2, &acc1 = a3;                                                                           \
+            SBLAS_DPP_FMA4x2(K0, K1, K2, K3, d0, d1, d2, d3);                                                        \
+        }                                                                                                            \
+    }
+        SBLAS_ROWS_BLOCK(0, 1, 2, 3)
+        if (mx > 4) SBLAS_ROWS_BLOCK(4, 5, 6, 7)
+        if (mx > 8) SBLAS_ROWS_BLOCK(8, 9, 10, 11)
+        if (mx > 12) SBLAS_ROWS_BLOCK(12, 13, 14, 15)
+#undef SBLAS_ROWS_BLOCK
+#undef SBLAS_LD
+    }
+    if (k == 0) row_mine[rr] = mine ? 1 : 0;
+    ctile[2 * k][rr] = a0;
+    ctile[2 * k + 1][rr] = a1;
+    ctile[32 + 2 * k][rr] = a2;
+    ctile[33 + 2 * k][rr] = a3;
+    __syncthreads();
+    const int nrows = min(ROWS_PANEL, rows - row0);
+    const int ncols = min(64, n - col0);
+    for (int idx = threadIdx.x; idx < 64 * ROWS_PANEL; idx += 1024) {
+        const int r = idx % ROWS_PANEL, j = idx / ROWS_PANEL;
+        if (r < nrows && j < ncols && row_mine[r]) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j][r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SpMV: LPR lanes per row (a power of two, 4..64), 256/LPR rows per workgroup.  The lanes of a
 // group stride through the row's nonzeros (coalesced col_idx / val streams, x gathered through
 // L2), then the partial sums are folded with xor-shuffles inside the wave -- the wave64 successor of
@@ -2993,12 +3097,13 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
-        if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_AUTO || variant == SPMM_VARIANT_WINDOW2 ||
+        if (variant == SPMM_VARIANT_DIRECT_DPP || variant == SPMM_VARIANT_DIRECT_ROWS || variant == SPMM_VARIANT_AUTO ||
+            variant == SPMM_VARIANT_WINDOW2 ||
             variant == SPMM_VARIANT_WINDOW3 || variant == SPMM_VARIANT_WINDOW4 || variant == SPMM_VARIANT_WINDOW5 ||
             variant == SPMM_VARIANT_WINDOW6) {
             const int2 *info = nullptr;
             int info_rows = 1;
-            if (variant != SPMM_VARIANT_DIRECT_DPP) {
+            if (variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
                 const bool gen4 = (variant == SPMM_VARIANT_WINDOW4);
@@ -3125,7 +3230,13 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             const size_t pad = dl ? (size_t)atoi(dl) : (ldbt == 64 ? 0 : 90000);
             const char *dm = getenv("SBLAS_DIRECT_MAP"); /* experiments: interleave | contiguous; default: by span */
             const int interleave = (dm && !strcmp(dm, "interleave")) ? 1 : (dm && !strcmp(dm, "contiguous")) ? 0 : -1;
-            if (ldbt == 64 && n <= 32) {
+            const double avg_row = rows > 0 ? (double)nnz / (double)rows : 0.0;
+            if (n > 32 && (variant == SPMM_VARIANT_DIRECT_ROWS || (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < 32.0))) {
+                // short rows: four rows per wave
+                const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
+                hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
+                                   cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+            } else if (ldbt == 64 && n <= 32) {
                 dim3 grid((unsigned)wide_panels, 1u);
                 if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,

@@ -105,7 +105,7 @@ def test_ash85_spmm_known_answers(env, ash85, key):
     assert oracle.lib().orc_check_equal(ref, got, got.size) == 1          # the reference's own criterion (1e-3 abs)
 
 
-@pytest.mark.parametrize("variant", ["auto", "dpp", "direct", "win2", "win3", "win4", "win5", "win6"])
+@pytest.mark.parametrize("variant", ["auto", "dpp", "rows", "direct", "win2", "win3", "win4", "win5", "win6"])
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 130, 256])
 def test_spmm_every_column_count(env, variant_env, variant, n):
     sblas, oracle, torch, dev = env
@@ -183,7 +183,7 @@ def test_spmm_nonfinite_b_rows_not_referenced_stay_out(env, variant_env):
     B[:, 0] = np.nan
     B = np.ascontiguousarray(B).reshape(-1)
     C0 = rng.standard_normal(rows * n)
-    for variant in ("dpp", "win64", "win2", "win3", "win4", "win5", "win6", "auto"):
+    for variant in ("dpp", "rows", "win64", "win2", "win3", "win4", "win5", "win6", "auto"):
         variant_env(variant)
         got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
         ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
@@ -446,7 +446,7 @@ def test_full_size_properties(env):
 # ---------------------------------------------------------------------------------------------------------
 # the windowed (row panel x LDS B tile) kernel and its per-panel fallback
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["direct", "dpp", "win2", "win3", "win4", "win5", "win6", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
+@pytest.mark.parametrize("variant", ["direct", "dpp", "rows", "win2", "win3", "win4", "win5", "win6", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
 @pytest.mark.parametrize("shape", [(1000, 40, 100, 64), (777, 60, 300, 130), (200, 30, 20, 64), (90, 80, 45, 256)])
 def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     """Banded, ascending rows: dense enough over their span that the windowed path is taken.  Covers several
