@@ -2088,27 +2088,6 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
         const int cbuf = (t - t_lo) & 1;
         // next tile (that buffer was last read before the previous barrier)
         if (loader && t < t_hi) dma_part(t + 1, cbuf ^ 1, 0, 16);
-        if (loader && !(ABL && (ablate & 0x80000))) {
-            // L2 warm-up for the workgroup that will follow this one on the CU (32 panels further down this XCD's range):
-            // its verdict, its row pointers and -- two tiles later -- the lines of C it will update.  The loader waves
-            // have the time; the prologue and epilogue of a panel are chains of dependent HBM round trips otherwise.
-            const int j = t - t_lo, pn = panel + 32, r0n = pn * panel_rows;
-            const void *touch = nullptr;
-            const int L = (wave - 12) * 64 + lane;
-            if (pn < npanels && r0n < rows) {
-                if (j == 1 && L == 0) touch = info + pn;
-                else if (j == 1 && L <= 8 && (L - 1) * 32 <= panel_rows) touch = rowptr + min(r0n + (L - 1) * 32, rows);
-                else if ((j == 2 || j == 3) && beta != 0.0) {
-                    const int id = L + 256 * (j - 2), col = id / 7, piece = id % 7;
-                    const int r = r0n + piece * 16;
-                    if (col < min(64, n - col0) && piece * 16 < panel_rows && r < rows) touch = C + (int64_t)(col0 + col) * ldc + r;
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(touch != nullptr) != 0ull) {
-                const void *a = touch ? touch : (const void *)info;
-                asm volatile("global_load_dword %0, %1, off" : "+v"(dummy) : "v"(a) : "memory");
-            }
-        }
         const int tile_lo = t * W2_ROWS;
         const unsigned tile_base = (unsigned)(uintptr_t)(smem + cbuf * W2_TILE);
         const unsigned lb = tile_base + (unsigned)k * 16u;

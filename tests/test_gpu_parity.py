@@ -662,6 +662,28 @@ def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
         assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, avg, alpha, beta)
 
 
+def test_spmm_kernel_event_hook(env):
+    """sblas_hip_debug_spmm_kernel_events: the launcher brackets the dominant stage-2 kernel with HIP events while the
+    hook is on (bench.py times its roofline object with it); off again, launches record nothing new."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, n = 3000, 64
+    rp, ci, v = synth.banded(rows, 120, 500)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    B = torch.rand(rows * n, dtype=torch.float64, device=dev)
+    C = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), n) // 8, dtype=torch.float64, device=dev)
+    sblas.kernel_events(True)
+    try:
+        sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, n, 1.0, 0.0, C, rows, ws)
+        ms = sblas.last_kernel_ms()
+        assert 0.0 < ms < 50.0
+    finally:
+        sblas.kernel_events(False)
+    ref = oracle.spmm(rows, rows, n, *A.h, B.cpu().numpy(), np.zeros(rows * n), 1.0, 0.0)
+    assert close(C.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("n", [64, 200, 256, 300])
 def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
     """BASELINE config 5 shape problem (Queen_4147, N = 256: the row-major copy of B is 8.5 GB) in miniature: with the
