@@ -12,8 +12,9 @@
 //                                kept as regression cases of the parity suite
 // SpMV  y = alpha*A*x + beta*y
 //   spmv_csr_lds_kernel<RW,S>    DEFAULT above 96 nonzeros per row: x window of a 16-row block in LDS
-//   spmv_csr_seg_kernel<R,S>     DEFAULT for 33..96 per row: R rows per wave, segmented reduction
-//   spmv_csr_kernel<LPR>         DEFAULT up to 32 per row: LPR lanes per row, xor-shuffle fold
+//   spmv_csr_seg_kernel<R,S>     DEFAULT for 49..96 per row: R rows per wave, segmented reduction
+//   spmv_csr_stream_kernel       DEFAULT for 6..48 per row: 256 rows per block streamed through LDS
+//   spmv_csr_kernel<LPR>         DEFAULT up to 5 per row: LPR lanes per row, xor-shuffle fold
 //   spmv_csr_{burst,window,flat}_kernel   experiments (SBLAS_SPMV_VARIANT)
 // Epilogues and merges
 //   axpby_kernel                 y = beta*y + alpha*x                                        (kernel.h:27-38)
@@ -2565,7 +2566,95 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// SpMV for medium rows (25..96 nonzeros), segmented form.  With one row per wave a 73-nonzero row (Queen_4147) fills
+// SpMV for short and medium rows (5..48 nonzeros per row on average), stream form.  The lanes-per-row kernel gives every row a lane group
+// of 4..32 lanes: a 5-nonzero row keeps 4 of 8 lanes busy for two trips, and the stencil-like matrices that have such
+// rows run at 2.6-3.3 TB/s.  Here a 256-thread block owns 256 consecutive rows, i.e. ONE contiguous run of nonzeros:
+// all threads stream it (thread t takes nonzeros t, t + 256, ...; every lane busy, fully coalesced), park the
+// products in LDS, and thread r then adds up the products of row r in CSR order.  A block whose rows hold more than
+// the LDS can take (longer rows among the short ones) takes its rows in several runs.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_ROWS = 256;
+constexpr int ST_CAP = 6144; // products per block (48 KiB + skew): three blocks per CU
+__device__ __forceinline__ int st_skew(int q) { return q + (q >> 5); } // rows of equal length: spread the LDS banks
+__global__ __launch_bounds__(ST_ROWS) void spmv_csr_stream_kernel(int rows, const int *__restrict__ rowptr,
+                                                                 const int *__restrict__ colidx,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ x, double alpha, double beta,
+                                                                 double *__restrict__ y)
+{
+    __shared__ double prod[ST_CAP + ST_CAP / 32 + 1];
+    __shared__ int sp[ST_ROWS + 1];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * ST_ROWS;
+    const int nr = min(ST_ROWS, rows - row0);
+    if (tid < nr) sp[tid] = rowptr[row0 + tid];
+    if (tid == 0) sp[nr] = rowptr[row0 + nr];
+    __syncthreads();
+    __shared__ double wsum[ST_ROWS / 64];
+    // The block's rows are taken in runs whose nonzeros fit the LDS: normally one run (all 256 rows); a block with
+    // longer rows takes several, and a single row beyond the capacity is summed by the whole block.
+    for (int r0 = 0; r0 < nr;) {
+        const int base = sp[r0];
+        int r1 = nr;
+        if (sp[nr] - base > ST_CAP) { // largest r1 with sp[r1] - base <= ST_CAP (block-uniform: every thread searches)
+            int lo = r0, hi = nr;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sp[mid] - base <= ST_CAP) lo = mid; else hi = mid - 1;
+            }
+            r1 = lo;
+        }
+        if (r1 == r0) { // one row longer than the LDS capacity
+            double sum = 0.0;
+            for (int p = base + tid; p < sp[r0 + 1]; p += ST_ROWS) sum = fma(val[p], x[colidx[p]], sum);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+            if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < ST_ROWS / 64; ++w) t += wsum[w];
+                const double res = alpha * t;
+                y[row0 + r0] = (beta == 0.0) ? res : fma(beta, y[row0 + r0], res);
+            }
+            __syncthreads();
+            r0 += 1;
+            continue;
+        }
+        const int total = sp[r1] - base;
+        // UN nonzeros per thread in flight (clamped indices instead of predicates: no waits between the loads)
+        constexpr int UN = 8;
+        const int lastp = max(total - 1, 0);
+        for (int p = tid; p < total; p += UN * ST_ROWS) {
+            int c[UN];
+            double a[UN], xv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int q = min(p + u * ST_ROWS, lastp);
+                c[u] = colidx[base + q];
+                a[u] = val[base + q];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (p + u * ST_ROWS < total) prod[st_skew(p + u * ST_ROWS)] = a[u] * xv[u];
+        }
+        __syncthreads();
+        if (tid >= r0 && tid < r1) {
+            double sum = 0.0;
+            for (int q = sp[tid] - base, e = sp[tid + 1] - base; q < e; ++q) sum += prod[st_skew(q)];
+            const double res = alpha * sum;
+            y[row0 + tid] = (beta == 0.0) ? res : fma(beta, y[row0 + tid], res);
+        }
+        if (r1 < nr) __syncthreads(); // prod is reused by the next run
+        r0 = r1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for medium rows (49..96 nonzeros), segmented form.  With one row per wave a 73-nonzero row (Queen_4147) fills
 // 57 % of two 64-lane slices and walks two dependent trips: 2.3 TB/s.  Here a wave owns R consecutive rows -- one
 // contiguous run of nonzeros -- and streams it in unpredicated slices of 64 (clamped indices, S slices in flight:
 // 91 % of the lanes busy for R = 4, S = 5 at 73 per row); every lane knows the row of its entry from the R + 1 row
@@ -3370,7 +3459,16 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     // lanes-per-row kernel wins)
     if (!sv || !*sv || !strcmp(sv, "auto")) {
         if (avg > 48.0 && avg <= 96.0) SBLAS_SPMV_SEG(4, 5);
-        if (avg > 24.0 && avg <= 48.0) SBLAS_SPMV_SEG(8, 5); // (27 per row, stencil-like: 506 us vs 557 us; 28, scattered: 91 vs 94)
+    }
+    // short and medium rows (5 < avg <= 48): 256 rows per block streamed through LDS, in runs of up to 6144 products
+    // (stencil-like rows of 7 / 13 / 27: 108 / 177 / 344 us vs 143 / 277 / 498 us for the lanes-per-row and segmented
+    // kernels; banded-random rows of 14 / 20 / 28 / 36 / 48: 46 / 62 / 85 / 116 / 161 vs 49 / 71 / 94 / 128 / 194).
+    // Above 48 the segmented kernel stays (Queen-like rows of 69: 52 us vs 85 us for the stream form, which needs
+    // three runs per block there); at 5 and below the lanes-per-row kernel is as fast or faster.
+    if ((sv && !strcmp(sv, "stream")) || ((!sv || !*sv || !strcmp(sv, "auto")) && avg > 5.0 && avg <= 48.0)) {
+        hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0, s, rows,
+                           rowptr, colidx, val, x, alpha, beta, y);
+        return hipGetLastError();
     }
     if (sv && !strcmp(sv, "seg4")) SBLAS_SPMV_SEG(4, 5);
     if (sv && !strcmp(sv, "seg3")) SBLAS_SPMV_SEG(3, 4);

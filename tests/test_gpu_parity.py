@@ -643,7 +643,7 @@ def test_spmv_lds_window_fetch_paths(env, xoff, K):
     assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), 1.5, -1.0))
 
 
-@pytest.mark.parametrize("variant", ["seg2", "seg3", "seg4", "seg8"])
+@pytest.mark.parametrize("variant", ["seg2", "seg3", "seg4", "seg8", "stream"])
 @pytest.mark.parametrize("avg", [2, 30, 73, 150])
 def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
     """The segmented kernel (R rows per wave, one contiguous run of nonzeros, per-row accumulation by row pointer
@@ -660,6 +660,33 @@ def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
         x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
         sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
         assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, avg, alpha, beta)
+
+
+@pytest.mark.parametrize("variant", ["stream", "auto"])
+def test_spmv_stream_runs_and_oversize_rows(env, spmv_variant_env, variant):
+    """The short-row stream kernel parks a block's products in LDS (6144 per run): a block whose 256 rows hold more
+    is taken in several runs, and a single row beyond the capacity is summed by the whole block.  Rows of 21 on
+    average with one block of 40-nonzero rows, one row of 7000 and one of 6144 exactly; the row count is not a
+    multiple of 256."""
+    sblas, oracle, torch, dev = env
+    spmv_variant_env(variant)
+    rng = np.random.default_rng(5)
+    M, K = 2000, 9000
+    lens = rng.integers(0, 20, M)
+    lens[300:560] = 40
+    lens[700] = 7000
+    lens[1500] = 6144
+    lens[M - 1] = 3
+    rp = np.zeros(M + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(lens)
+    ci = np.concatenate([rng.choice(K, l, replace=False) for l in lens]).astype(np.int32)
+    v = rng.standard_normal(len(ci))
+    A = Dev(torch, dev, rp, ci, v, K)
+    xh, yh = rng.standard_normal(K), rng.standard_normal(M)
+    for alpha, beta in ((1.0, 1.0), (2.0, 0.0)):
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
+        assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, alpha, beta)
 
 
 def test_spmm_kernel_event_hook(env):
