@@ -25,6 +25,7 @@
 // spmv.h:104-106) and its one utility kernel (kernel.h:27-38).  Everything is written for
 // 64-wide wavefronts; there is no 32-lane code path.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
                                                              const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx, int max_row_len,
                                                              float min_density, int2 *__restrict__ info,
-                                                             int exclude_tail)
+                                                             int exclude_tail, int epoch)
 {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -614,6 +615,10 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         // the middle panel's column span, copied to the slot after the verdicts (one writer): the direct kernel takes
         // it as the band width of the matrix when it chooses its panel -> XCD map
         if (p == npanels / 2) info[npanels] = make_int2(last >= first ? last - first + 1 : 0, 0);
+        // "this call left work for the direct kernel": the launch's epoch in the second spare slot (every writer
+        // stores the same value).  The direct kernel leaves at once when the slot holds anything else -- an
+        // optimisation only: a stale or accidental match merely sends it through its per-panel checks.
+        if (!ok) info[npanels + 1].x = epoch;
     }
 }
 // column span of a classified panel (0 for an empty one)
@@ -2256,13 +2261,17 @@ template <int GROUPS>
 __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave)
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave,
+    int epoch)
 {
     static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "lane groups of 64, 32 or 16 lanes");
     constexpr int TILE_COLS = 128 / GROUPS;
     constexpr int PER_STEP = 16 * GROUPS; // nonzeros handled by one 16-slot sweep
     constexpr int GLANES = 64 / GROUPS;   // lanes that share a nonzero
     __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
+    // every panel windowed (the bench matrix): one scalar load of one shared address and out, instead of two
+    // dependent loads per workgroup (4500 workgroups of early exits took 16 us of a 340 us step)
+    if (info != nullptr && info[(rows + info_panel_rows - 1) / info_panel_rows + 1].x != epoch) return;
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
@@ -2436,10 +2445,12 @@ constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
 __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave)
+    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave,
+    int epoch)
 {
     __shared__ double ctile[64][ROWS_PANEL + 1];
     __shared__ int row_mine[ROWS_PANEL];
+    if (info != nullptr && info[(rows + info_panel_rows - 1) / info_panel_rows + 1].x != epoch) return; // nothing direct
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     const int k = lane & 15, q = lane >> 4;
@@ -3192,6 +3203,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             variant == SPMM_VARIANT_WINDOW6) {
             const int2 *info = nullptr;
             int info_rows = 1;
+            static std::atomic<int> g_epoch{1};
+            const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed); // tags this call's classifier verdicts
             if (variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
@@ -3221,7 +3234,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                     const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments: "<rows>" or "<rows>,<groups>" */
                     if (pr) {
                         int r = atoi(pr), g = strchr(pr, ',') ? atoi(strchr(pr, ',') + 1) : (r % 12 == 0 && r > 128 ? 3 : 2);
-                        if ((g == 2 || g == 3) && r >= 4 * g && r <= 48 * g && r % (4 * g) == 0) {
+                        if ((g == 2 || g == 3) && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) { // (workspace: a verdict per 32 rows)
                             info_rows = r;
                             gen6_g = g;
                         }
@@ -3238,7 +3251,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    gen6 ? (1 << 24) : (gen4 || gen5) ? 0x7fffffff : ch * 64,
                                    /* streaming generations: a (row, tile) visit costs what ~8 nonzeros cost in the
                                       direct kernel, so ask for 8 per row and 128-column tile on average */
-                                   (gen4 || gen5 || gen6) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0);
+                                   (gen4 || gen5 || gen6) ? (float)info_rows / 16.0f : 1.0f, winfo, gen5 ? 1 : 0, epoch);
                 dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
                 const char *ab = getenv("SBLAS_ABLATE"); /* diagnostics only: wrong results when set */
                 const int ablate = ab ? atoi(ab) : 0;
@@ -3324,22 +3337,22 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 // short rows: four rows per wave
                 const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
                 hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
-                                   cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+                                   cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave, epoch);
             } else if (ldbt == 64 && n <= 32) {
                 dim3 grid((unsigned)wide_panels, 1u);
                 if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave, epoch);
             } else if (ldbt == 64) {
                 dim3 grid((unsigned)wide_panels, 1u);
                 if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<2>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave, epoch);
             } else {
                 dim3 grid((unsigned)wide_panels, (unsigned)(ldbt / 128));
                 if (pad) (void)hipFuncSetAttribute((const void *)spmm_direct_dpp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, grid, dim3(WIDE_WAVES * 64), pad, s, rows, cols,
-                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave);
+                                   wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave, epoch);
             }
         } else if (variant == SPMM_VARIANT_DIRECT) {
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
