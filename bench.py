@@ -135,12 +135,37 @@ def cpu_baseline(rows, cols, n, rp, ci, v, Bh, budget_s):
     return out
 
 
+def settle(torch, step, max_blocks=25, block=20):
+    """Untimed steps until the device has left its idle clocks: after a pause an MI355X needs ~150 steps (50 ms) of
+    this load before the step time stops falling (0.33 -> 0.27 ms, tools/graph_step.py).  Blocks of `block` steps,
+    stop when two blocks in a row are no more than 1 % faster than the best before them; returns the steps run."""
+    best, flat, done = None, 0, 0
+    for _ in range(max_blocks):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(block):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        done += block
+        ms = e0.elapsed_time(e1)
+        if best is not None and ms > 0.99 * best:
+            flat += 1
+            if flat == 2:
+                break
+        else:
+            flat = 0
+        best = ms if best is None else min(best, ms)
+    return done
+
+
 def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp, ci, v):
     """y = A*x + y on every rank (replicas: SpMV has no column dimension to split), HIP-event kernel time."""
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rowptr, colidx, val = d(rp), d(ci), d(v)
     x = torch.ones(cols, dtype=torch.float64, device=dev)
     y = torch.ones(rows, dtype=torch.float64, device=dev)
+    settled = 0 if args.no_settle else settle(torch, lambda: S.spmv(rows, cols, rowptr, colidx, val, x, 1.0, 1.0, y))
     for _ in range(args.warmup):
         S.spmv(rows, cols, rowptr, colidx, val, x, 1.0, 1.0, y)
     torch.cuda.synchronize()
@@ -166,7 +191,7 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
     # y = 1 + steps_total * A*1  -> compare with row sums (exact structure check)
     if rank == 0:
         rs = np.add.reduceat(v, rp[:-1].astype(np.int64)) if nnz else np.zeros(rows)
-        want = 1.0 + (args.warmup + args.steps) * rs
+        want = 1.0 + (settled + args.warmup + args.steps) * rs
         if not np.allclose(y.cpu().numpy(), want, rtol=1e-9, atol=1e-9):
             raise SystemExit("spmv bench result mismatch")
         sp_kernel = ("spmv_csr_lds_kernel" if nnz > 96 * rows and os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto", "lds")
@@ -175,6 +200,7 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
                               if os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto") else (None, None))
         out = {"metric": "SpMV GFLOP/s (2*nnz/t), CSR fp64", "value": round(world * 2.0 * nnz * args.steps / elapsed / 1e9, 2),
                "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "settle_steps": settled,
                "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
                "config": {"workload": "SpMV y=A*x+y, %s, nnz=%d, replicas only" % (name, nnz), "rows": rows, "nnz": nnz},
@@ -195,6 +221,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the untimed clock-settling steps in front of the warm-up (cold-start figure)")
     ap.add_argument("--ncols", type=int, default=64, help="dense columns per GPU (method 1)")
     ap.add_argument("--matrix", type=str, default=None, help="MatrixMarket file instead of the synthetic stand-in")
     ap.add_argument("--scale", type=float, default=1.0, help="row-count scale of the synthetic stand-in (rehearsal only)")
@@ -256,6 +284,7 @@ def main():
         S.dense_to_rowmajor(cols, n, B, cols, Bt)
         S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
 
+    settled = 0 if args.no_settle else settle(torch, step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -281,8 +310,25 @@ def main():
     s2 = [e[1].elapsed_time(e[2]) for e in ev]
     t_stage2 = float(np.mean(s2)) * 1e-3
 
+    # the dominant stage-2 kernel alone: HIP events recorded by the launcher around that one launch (a diagnostic hook
+    # of the C ABI), ten extra steps straight after the timed region (clocks still settled)
+    t_dom, extra_steps = None, 0
+    try:
+        S.kernel_events(True)
+        samples = []
+        for _ in range(10):
+            step()
+            extra_steps += 1
+            samples.append(S.last_kernel_ms())
+        t_dom = float(np.mean(samples)) * 1e-3
+    except S.SblasError:
+        t_dom = None                                # (variants that never launch a windowed kernel)
+    finally:
+        S.kernel_events(False)
+    t_roof = t_dom if t_dom else t_stage2
+
     # correctness guard on this rank's result: C = 1 + (warmup+steps) * A*B on 64 sampled rows vs the oracle
-    total_steps = args.warmup + args.steps
+    total_steps = settled + args.warmup + args.steps + extra_steps
     check = None
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -296,21 +342,6 @@ def main():
         if not check and not os.environ.get("SBLAS_ABLATE"):   # (SBLAS_ABLATE: diagnostic builds compute garbage on purpose)
             raise SystemExit("bench result does not match the oracle: max diff %g" % np.abs(got - want).max())
 
-    # the dominant stage-2 kernel alone: HIP events recorded by the launcher around that one launch (a diagnostic hook
-    # of the C ABI), ten extra steps after the timed region and the result check
-    t_dom = None
-    try:
-        S.kernel_events(True)
-        samples = []
-        for _ in range(10):
-            step()
-            samples.append(S.last_kernel_ms())
-        t_dom = float(np.mean(samples)) * 1e-3
-    except S.SblasError:
-        t_dom = None                                # (variants that never launch a windowed kernel)
-    finally:
-        S.kernel_events(False)
-    t_roof = t_dom if t_dom else t_stage2
 
     flops_step = 2.0 * nnz * n                      # per GPU
     value = world * flops_step * args.steps / elapsed / 1e9
@@ -322,6 +353,7 @@ def main():
     out = {
         "metric": "SpMM GFLOP/s (2*nnz*N/t), CSR x dense N=64, fp64",
         "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "settle_steps": settled,   # untimed steps in front of the warm-up until the clocks have settled (see settle())
         "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.matrix else "file",
         "config": {"workload": "SpMM method-1 (dense-B column partition), %s, nnz=%d, N=%d columns per GPU, alpha=beta=1, "

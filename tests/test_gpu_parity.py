@@ -757,3 +757,41 @@ def test_spmm_queen_like_n256(env, variant_env, variant):
     assert close(got, ref)
     if variant == "auto":
         assert st[0] == 0 and st[1] > 0 and st[2] == 0        # nothing windowed, nothing fell back
+
+
+@pytest.mark.parametrize("kind", ["banded", "mixed"])
+def test_spmm_and_spmv_inside_a_hip_graph(env, kind):
+    """The product path is stream-ordered only (no host synchronisation, no allocation, no host read-back): a call
+    can be captured into a HIP graph and replayed on new values in the same buffers.  Banded rows take the LDS-tiled
+    kernel, the mixed matrix sends most panels to the direct kernel."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, n = 4000, 64
+    if kind == "banded":
+        rp, ci, v = synth.banded(rows, 150, 600)
+    else:
+        rp, ci, v = synth.random_csr(rows, rows, 40, seed=3, sorted_rows=True, empty_every=11, long_row=(17, 2500))
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(11)
+    B = torch.from_numpy(rng.standard_normal(rows * n)).to(dev)
+    C = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+    x = torch.from_numpy(rng.standard_normal(rows)).to(dev)
+    y = torch.zeros(rows, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), n) // 8, dtype=torch.float64, device=dev)
+    sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, n, 1.0, 0.0, C, rows, ws)   # warm-up outside the capture
+    sblas.spmv(rows, rows, A.rowptr, A.colidx, A.val, x, 1.0, 0.0, y)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, n, 2.0, 0.0, C, rows, ws)
+        sblas.spmv(rows, rows, A.rowptr, A.colidx, A.val, x, 2.0, 0.0, y)
+    for rep in range(2):                                       # new values in the captured buffers, then replay
+        Bh, xh = rng.standard_normal(rows * n), rng.standard_normal(rows)
+        B.copy_(torch.from_numpy(Bh).to(dev))
+        x.copy_(torch.from_numpy(xh).to(dev))
+        C.fill_(7.0)
+        y.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert close(C.cpu().numpy(), oracle.spmm(rows, rows, n, *A.h, Bh, np.zeros(rows * n), 2.0, 0.0)), (kind, rep)
+        assert close(y.cpu().numpy(), oracle.spmv(rows, *A.h, xh, np.zeros(rows), 2.0, 0.0)), (kind, rep)

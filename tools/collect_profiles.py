@@ -13,6 +13,29 @@ for op in ("spmm", "spmv"):
         shutil.copy(f[0], f"{dst}/{rnd}_{op}_bench_kernel_stats.csv")
         for row in csv.DictReader(open(f[0])):
             print(op, row["Name"][:60], row["Calls"], "avg ns", row["AverageNs"])
+# per-kernel durations of the same run split by phase: bench.py first runs untimed clock-settling steps (the device
+# leaves its idle clocks over ~150 steps), so the all-calls average of --stats mixes cold and settled launches; the
+# last 60 launches of a kernel are the timed region (50) + the launcher-event steps (10)
+for op in ("spmm", "spmv"):
+    f = sorted(glob.glob(f"{src}/{op}/*/*kernel_trace.csv"), key=os.path.getmtime, reverse=True)
+    if not f:
+        continue
+    per = collections.defaultdict(list)
+    for row in csv.DictReader(open(f[0])):
+        if "sblas::" in row["Kernel_Name"]:
+            per[row["Kernel_Name"].split("(")[0].replace("void ", "")].append(
+                (int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    doc = {"source": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py" +
+                     (" --op spmv" if op == "spmv" else "") + " --steps 50 --warmup 5 (kernel_trace.csv of the run "
+                     "whose --stats summary is %s_%s_bench_kernel_stats.csv)" % (rnd, op), "kernels": {}}
+    for k, v in per.items():
+        d = [x[1] for x in sorted(v)]
+        tail = d[-60:] if op == "spmm" else d[-100:]
+        doc["kernels"][k] = {"calls": len(d), "avg_ns_all_calls": sum(d) / len(d), "first_10_avg_ns": sum(d[:10]) / len(d[:10]),
+                             "timed_region_calls": len(tail), "timed_region_avg_ns": sum(tail) / len(tail),
+                             "min_ns": min(d)}
+        print(op, "phases", k[:50], doc["kernels"][k])
+    json.dump(doc, open(f"{dst}/{rnd}_{op}_kernel_phases.json", "w"), indent=1)
 for name in ("bench_default", "bench_spmv"):
     if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
         shutil.copy(f"{src}/{name}.json", f"{dst}/{rnd}_{name}.json")
