@@ -279,26 +279,19 @@ def main():
     Bt = torch.empty(S.spmm_workspace_bytes(rows, cols, nnz, n) // 8, dtype=torch.float64, device=dev)   # the C ABI's workspace
 
     def step():
-        # == sblas_hip_spmm_csr_f64_i32: the same two launches, issued separately only so that an event can
-        # sit between them (per-kernel timing for the roofline object)
-        S.dense_to_rowmajor(cols, n, B, cols, Bt)
-        S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
+        # the drop-in boundary itself: sblas_hip_spmm_csr_f64_i32 (staging + classifier in one launch, then stage 2)
+        S.spmm(rows, cols, rowptr, colidx, val, B, cols, n, 1.0, 1.0, C, rows, Bt)
 
     settled = 0 if args.no_settle else settle(torch, step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        S.dense_to_rowmajor(cols, n, B, cols, Bt)
-        ev[k][1].record()
-        S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
-        ev[k][2].record()
+        step()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -306,25 +299,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # per-kernel times, ten extra steps straight after the timed region (clocks still settled) through the SPLIT entry
+    # points (staging | classifier + stage 2 -- the same kernels, one launch more than the fused entry): an event
+    # between the stages, and the launcher's own HIP events around the dominant stage-2 launch alone (a diagnostic
+    # hook of the C ABI).  Through the fused entry the hook's first event would sit straight behind the staging
+    # launch, and the L2 write-back of the 37 MB it wrote (~10 us) would be billed to the kernel behind it.
+    t_dom, extra_steps, samples = None, 0, []
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(10)]
+    try:
+        S.kernel_events(True)
+        for k in range(10):
+            ev[k][0].record()
+            S.dense_to_rowmajor(cols, n, B, cols, Bt)
+            ev[k][1].record()
+            S.spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, 1.0, 1.0, C, rows)
+            ev[k][2].record()
+            extra_steps += 1
+            try:
+                samples.append(S.last_kernel_ms())
+            except S.SblasError:
+                pass                                # (variants that never launch a windowed kernel)
+    finally:
+        S.kernel_events(False)
+    torch.cuda.synchronize()
+    t_dom = float(np.mean(samples)) * 1e-3 if samples else None
     t_stage1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     s2 = [e[1].elapsed_time(e[2]) for e in ev]
     t_stage2 = float(np.mean(s2)) * 1e-3
-
-    # the dominant stage-2 kernel alone: HIP events recorded by the launcher around that one launch (a diagnostic hook
-    # of the C ABI), ten extra steps straight after the timed region (clocks still settled)
-    t_dom, extra_steps = None, 0
-    try:
-        S.kernel_events(True)
-        samples = []
-        for _ in range(10):
-            step()
-            extra_steps += 1
-            samples.append(S.last_kernel_ms())
-        t_dom = float(np.mean(samples)) * 1e-3
-    except S.SblasError:
-        t_dom = None                                # (variants that never launch a windowed kernel)
-    finally:
-        S.kernel_events(False)
     t_roof = t_dom if t_dom else t_stage2
 
     # correctness guard on this rank's result: C = 1 + (warmup+steps) * A*B on 64 sampled rows vs the oracle

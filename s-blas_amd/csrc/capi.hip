@@ -167,10 +167,9 @@ int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t
                : SBLAS_E_HIP;
 }
 
-int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
-                                         const int32_t *rowptr, const int32_t *colidx, const double *val,
-                                         const double *Bt, int64_t ldbt, int64_t n, double alpha,
-                                         double beta, double *C, int64_t ldc)
+static int spmm_staged(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                       const int32_t *colidx, const double *val, const double *Bt, int64_t ldbt, int64_t n,
+                       double alpha, double beta, double *C, int64_t ldc, int pre_epoch)
 {
     if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val) || n < 0) return SBLAS_E_INVALID;
     if (rows == 0 || n == 0) return SBLAS_OK;
@@ -183,9 +182,17 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID; // 16-byte tile loads
     return sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, val, Bt, ldbt,
-                                       (int)n, alpha, beta, C, ldc, spmm_variant()) == hipSuccess
+                                       (int)n, alpha, beta, C, ldc, spmm_variant(), pre_epoch) == hipSuccess
                ? SBLAS_OK
                : SBLAS_E_HIP;
+}
+
+int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                                         const int32_t *rowptr, const int32_t *colidx, const double *val,
+                                         const double *Bt, int64_t ldbt, int64_t n, double alpha,
+                                         double beta, double *C, int64_t ldc)
+{
+    return spmm_staged(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, 0);
 }
 
 int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
@@ -204,10 +211,21 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     for (int64_t j0 = 0; j0 < n; j0 += w) { // one pass unless Bt would exceed the 32-bit offset window
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
         const int64_t ldbt = chunk_ldbt(cols, n, nj);
-        int rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt);
-        if (rc != SBLAS_OK) return rc;
-        rc = sblas_hip_spmm_csr_rowmajorB_f64_i32(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, nj, alpha,
-                                                  beta, C + j0 * ldc, ldc);
+        int rc, pre_epoch = 0;
+        if (spmm_variant() == sblas::SPMM_VARIANT_AUTO && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
+            ldbt_ok(ldbt, nj)) {
+            // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
+            DeviceScope scope(dev);
+            if (scope.err != hipSuccess) return SBLAS_E_HIP;
+            if (sblas::launch_stage_classify((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, (int)rows, rowptr,
+                                             colidx, &pre_epoch) != hipSuccess)
+                return SBLAS_E_HIP;
+        } else {
+            rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt);
+            if (rc != SBLAS_OK) return rc;
+        }
+        rc = spmm_staged(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, nj, alpha, beta, C + j0 * ldc, ldc,
+                         pre_epoch);
         if (rc != SBLAS_OK) return rc;
     }
     return SBLAS_OK;

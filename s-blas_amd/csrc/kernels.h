@@ -21,7 +21,9 @@ enum { SPMM_VARIANT_AUTO = 0, SPMM_VARIANT_DIRECT = 1, SPMM_VARIANT_WINDOW_R32 =
 constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (one int2 of workspace per panel; generation 6: 32)
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc, int variant);
+                                double beta, double *C, int64_t ldc, int variant, int pre_epoch = 0);
+hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int *epoch_out);
 hipError_t panel_stats(unsigned long long out[4], bool reset);
 hipError_t prof_stats(unsigned long long out[16], bool reset);
 hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,

@@ -2,6 +2,7 @@
 //
 // SpMM  C = alpha*A*B + beta*C   (stage 1 + stage 2; the launcher at the end of this file picks the kernels)
 //   dense_to_rowmajor_kernel     B (col-major) -> Bt (row-major, zero padded, one all-zero row)          [stage 1]
+//   stage_classify_kernel        stage 1 + classify_panels_kernel in one launch (fused C-ABI entry, default variant)
 //   classify_panels_kernel       per row panel: dense enough over its column span for the LDS-tiled kernel?
 //   spmm_window6_kernel<G>       DEFAULT for qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA
 //                                loader waves), one DPP row per matrix row, streaming windows of A (generation 6)
@@ -53,13 +54,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // run along j (contiguous in row-major Bt).  Row stride 65 doubles keeps both LDS phases
 // conflict-free for ds_read/write_b64 (lanes 0..31 land on distinct bank pairs).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, int64_t n,
-                                                               const double *__restrict__ B, int64_t ldb,
-                                                               double *__restrict__ Bt, int64_t ldbt)
+__device__ __forceinline__ void stage_tile(double (*tile)[65], int64_t k0, int64_t j0, int64_t cols, int64_t n,
+                                           const double *__restrict__ B, int64_t ldb, double *__restrict__ Bt,
+                                           int64_t ldbt)
 {
-    __shared__ double tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t k0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
     // all sixteen loads of a thread in flight before the first LDS store (the kernel is latency-bound otherwise:
     // 2.96 TB/s with four at a time)
     double v[16];
@@ -80,6 +79,13 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
         if (kr < cols && j < ldbt) Bt[kr * ldbt + j] = tile[tx][kk];
         if (kr == cols && j < ldbt) Bt[kr * ldbt + j] = 0.0; // the all-zero row masked DPP slots point at
     }
+}
+__global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, int64_t n,
+                                                               const double *__restrict__ B, int64_t ldb,
+                                                               double *__restrict__ Bt, int64_t ldbt)
+{
+    __shared__ double tile[64][65];
+    stage_tile(tile, (int64_t)blockIdx.x * 64, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -573,14 +579,12 @@ constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64
 
 // info[p] = (cmin, cmax) of panel p when it should take the windowed path, (1, 0) otherwise.
 // One wave per panel, one lane per row.
-__global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
-                                                             const int *__restrict__ rowptr,
-                                                             const int *__restrict__ colidx, int max_row_len,
-                                                             float min_density, int2 *__restrict__ info,
-                                                             int exclude_tail, int epoch)
+__device__ __forceinline__ void classify_panel(int p, int rows, int cols, int npanels, int panel_rows,
+                                               const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                                               int max_row_len, float min_density, int2 *__restrict__ info,
+                                               int exclude_tail, int epoch)
 {
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= npanels) return;
     int first = 0x7fffffff, last = -1, len = 0, mlen = 0;
     for (int rr = lane; rr < panel_rows; rr += WAVE) { // panels of up to 128 rows: two rows per lane
@@ -619,6 +623,33 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
         // stores the same value).  The direct kernel leaves at once when the slot holds anything else -- an
         // optimisation only: a stale or accidental match merely sends it through its per-panel checks.
         if (!ok) info[npanels + 1].x = epoch;
+    }
+}
+__global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
+                                                             const int *__restrict__ rowptr,
+                                                             const int *__restrict__ colidx, int max_row_len,
+                                                             float min_density, int2 *__restrict__ info,
+                                                             int exclude_tail, int epoch)
+{
+    classify_panel(blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx, max_row_len,
+                   min_density, info, exclude_tail, epoch);
+}
+// Stage 1 and the panel classifier in one launch (the fused C-ABI entry: both depend only on the call's inputs, and
+// the classifier's few dependent loads hide behind the staging traffic): workgroups [0, stage_blocks) x grid.y
+// transpose B, workgroups beyond (grid.y == 0 only) classify four panels each.
+__global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64_t n, const double *__restrict__ B,
+                                                            int64_t ldb, double *__restrict__ Bt, int64_t ldbt,
+                                                            int stage_blocks, int rows, int npanels, int panel_rows,
+                                                            const int *__restrict__ rowptr,
+                                                            const int *__restrict__ colidx, int max_row_len,
+                                                            float min_density, int2 *__restrict__ info, int epoch)
+{
+    __shared__ double tile[64][65];
+    if ((int)blockIdx.x < stage_blocks) {
+        stage_tile(tile, (int64_t)blockIdx.x * 64, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
+    } else if (blockIdx.y == 0) {
+        classify_panel(((int)blockIdx.x - stage_blocks) * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows,
+                       rowptr, colidx, max_row_len, min_density, info, 0, epoch);
     }
 }
 // column span of a classified panel (0 for an empty one)
@@ -3191,9 +3222,58 @@ hipError_t kernel_events_last_ms(float *ms)
     return hipEventElapsedTime(ms, g_kev[dev].a, g_kev[dev].b);
 }
 
+// Sixth generation, one workgroup per CU at a time: the groups per wave (2 or 3) and the panel height (a multiple of
+// the rows of a wave) that minimise rounds x (height + per-tile fixed cost).
+static void gen6_plan(int rows, int &info_rows, int &gen6_g)
+{
+    const int ncu = compute_units();
+    int best = 128;
+    long best_cost = -1;
+    gen6_g = 2;
+    for (int g = 2; g <= W6_GMAX; ++g)
+        for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
+            const long panels = (rows + r - 1) / r;
+            // measured on the bench matrix: three groups per wave cost ~15 % more per row
+            const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 40) * (g == 3 ? 23 : 20);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best = r;
+                gen6_g = g;
+            }
+        }
+    info_rows = best;
+    const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments: "<rows>" or "<rows>,<groups>" */
+    if (pr) {
+        int r = atoi(pr), g = strchr(pr, ',') ? atoi(strchr(pr, ',') + 1) : (r % 12 == 0 && r > 128 ? 3 : 2);
+        if ((g == 2 || g == 3) && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) { // (workspace: a verdict per 32 rows)
+            info_rows = r;
+            gen6_g = g;
+        }
+    }
+}
+
+static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts (see classify_panel)
+
+// Stage 1 + classifier of the default (sixth-generation) path in one launch; the epoch goes to launch_spmm_rowpanel.
+hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int *epoch_out)
+{
+    int info_rows = 0, g = 2;
+    gen6_plan(rows, info_rows, g);
+    const int np = (rows + info_rows - 1) / info_rows;
+    const int stage_blocks = (int)((cols + 1 + 63) / 64);
+    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    int2 *winfo = reinterpret_cast<int2 *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
+    dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
+    hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
+                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, winfo, epoch);
+    *epoch_out = epoch;
+    return hipGetLastError();
+}
+
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc, int variant)
+                                double beta, double *C, int64_t ldc, int variant, int pre_epoch)
 {
     const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
     if (ldbt >= 64) {
@@ -3203,8 +3283,9 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             variant == SPMM_VARIANT_WINDOW6) {
             const int2 *info = nullptr;
             int info_rows = 1;
-            static std::atomic<int> g_epoch{1};
-            const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed); // tags this call's classifier verdicts
+            // pre_epoch != 0: launch_stage_classify has classified the panels already (default variant only)
+            const bool preclassified = pre_epoch != 0 && variant == SPMM_VARIANT_AUTO;
+            const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
             if (variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS) {
                 // 1. classify row panels; 2. windowed kernel on the qualifying ones; 3. direct kernel on the rest
                 const bool gen2 = (variant == SPMM_VARIANT_WINDOW2);
@@ -3213,38 +3294,13 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 const bool gen6 = (variant == SPMM_VARIANT_WINDOW6 || variant == SPMM_VARIANT_AUTO);
                 info_rows = gen2 ? W2_PANEL : gen4 ? W4_PANEL : gen5 ? W5_PANEL : W3_PANEL;
                 int gen6_g = 2;
-                if (gen6) {
-                    // one workgroup per CU at a time: pick the groups per wave (2 or 3) and the panel height (a
-                    // multiple of the rows of a wave) that minimise rounds x (height + per-tile fixed cost)
-                    const int ncu = compute_units();
-                    int best = 128;
-                    long best_cost = -1;
-                    for (int g = 2; g <= W6_GMAX; ++g)
-                        for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
-                            const long panels = (rows + r - 1) / r;
-                            // measured on the bench matrix: three groups per wave cost ~15 % more per row
-                            const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 40) * (g == 3 ? 23 : 20);
-                            if (best_cost < 0 || cost < best_cost) {
-                                best_cost = cost;
-                                best = r;
-                                gen6_g = g;
-                            }
-                        }
-                    info_rows = best;
-                    const char *pr = getenv("SBLAS_SPMM_PANEL_ROWS"); /* experiments: "<rows>" or "<rows>,<groups>" */
-                    if (pr) {
-                        int r = atoi(pr), g = strchr(pr, ',') ? atoi(strchr(pr, ',') + 1) : (r % 12 == 0 && r > 128 ? 3 : 2);
-                        if ((g == 2 || g == 3) && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) { // (workspace: a verdict per 32 rows)
-                            info_rows = r;
-                            gen6_g = g;
-                        }
-                    }
-                }
+                if (gen6) gen6_plan(rows, info_rows, gen6_g);
                 int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
                 const int np = (rows + info_rows - 1) / info_rows;
                 const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
                 const int need = (int)(avg * 1.15 / 64.0) + 1;
                 const int ch = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 7;
+                if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols,
                                    np, info_rows, rowptr, colidx,
                                    /* generation 6 addresses a wave's 8-12 rows through 32-bit buffer offsets */
