@@ -50,33 +50,35 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1: Bt[k][j] = B[k + j*ldb]   (k < cols, j < n), Bt[k][j] = 0 for n <= j < ldbt.
-// 64 x 64 tile through LDS: global reads run along k (contiguous in col-major B), global writes
-// run along j (contiguous in row-major Bt).  Row stride 65 doubles keeps both LDS phases
-// conflict-free for ds_read/write_b64 (lanes 0..31 land on distinct bank pairs).
+// 32 (k) x 64 (j) tile through LDS: global reads run along k (contiguous in col-major B, 256 bytes per half-wave),
+// global writes run along j (contiguous in row-major Bt, 512 bytes per wave).  Row stride 33 doubles keeps both LDS
+// phases conflict-free for ds_read/write_b64.  17 KB of LDS per workgroup: nine workgroups per CU, so the 2252 tiles
+// of the bench shape are resident at once (64 x 64 tiles, 33 KB: four per CU, 1126 tiles = one round and a tenth).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_tile(double (*tile)[65], int64_t k0, int64_t j0, int64_t cols, int64_t n,
+constexpr int STAGE_K = 32;
+__device__ __forceinline__ void stage_tile(double (*tile)[STAGE_K + 1], int64_t k0, int64_t j0, int64_t cols, int64_t n,
                                            const double *__restrict__ B, int64_t ldb, double *__restrict__ Bt,
                                            int64_t ldbt)
 {
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    // all sixteen loads of a thread in flight before the first LDS store (the kernel is latency-bound otherwise:
-    // 2.96 TB/s with four at a time)
-    double v[16];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // all eight loads of a thread in flight before the first LDS store (the kernel is latency-bound otherwise)
+    double v[8];
     const int64_t k = k0 + tx;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int64_t j = j0 + ty + 4 * u;
+    for (int u = 0; u < 8; ++u) {
+        const int64_t j = j0 + ty + 8 * u;
         v[u] = (j < n && k < cols) ? B[k + j * ldb] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = v[u];
+    for (int u = 0; u < 8; ++u) tile[ty + 8 * u][tx] = v[u];
     __syncthreads();
-    const int64_t j = j0 + tx;
+    const int jl = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int64_t j = j0 + jl;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int kk = ty + 4 * u;
+    for (int u = 0; u < 8; ++u) {
+        const int kk = kq + 4 * u;
         const int64_t kr = k0 + kk;
-        if (kr < cols && j < ldbt) Bt[kr * ldbt + j] = tile[tx][kk];
+        if (kr < cols && j < ldbt) Bt[kr * ldbt + j] = tile[jl][kk];
         if (kr == cols && j < ldbt) Bt[kr * ldbt + j] = 0.0; // the all-zero row masked DPP slots point at
     }
 }
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
                                                                const double *__restrict__ B, int64_t ldb,
                                                                double *__restrict__ Bt, int64_t ldbt)
 {
-    __shared__ double tile[64][65];
-    stage_tile(tile, (int64_t)blockIdx.x * 64, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
+    __shared__ double tile[64][STAGE_K + 1];
+    stage_tile(tile, (int64_t)blockIdx.x * STAGE_K, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -635,8 +637,8 @@ __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols
                    min_density, info, exclude_tail, epoch);
 }
 // Stage 1 and the panel classifier in one launch (the fused C-ABI entry: both depend only on the call's inputs, and
-// the classifier's few dependent loads hide behind the staging traffic): workgroups [0, stage_blocks) x grid.y
-// transpose B, workgroups beyond (grid.y == 0 only) classify four panels each.
+// the classifier's few dependent loads hide behind the staging traffic): the first ceil(npanels / 4) workgroups
+// (grid.y == 0 only) classify four panels each, the stage_blocks x grid.y behind them transpose B.
 __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64_t n, const double *__restrict__ B,
                                                             int64_t ldb, double *__restrict__ Bt, int64_t ldbt,
                                                             int stage_blocks, int rows, int npanels, int panel_rows,
@@ -644,12 +646,16 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                                                             const int *__restrict__ colidx, int max_row_len,
                                                             float min_density, int2 *__restrict__ info, int epoch)
 {
-    __shared__ double tile[64][65];
-    if ((int)blockIdx.x < stage_blocks) {
-        stage_tile(tile, (int64_t)blockIdx.x * 64, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
+    __shared__ double tile[64][STAGE_K + 1];
+    // the classifier's workgroups come first in the grid: their chain of dependent loads starts at once and ends
+    // under the staging traffic (placed last they stuck out by ~3 us)
+    const int cblocks = (npanels + 3) / 4;
+    if ((int)blockIdx.x >= cblocks) {
+        stage_tile(tile, (int64_t)((int)blockIdx.x - cblocks) * STAGE_K, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt,
+                   ldbt);
     } else if (blockIdx.y == 0) {
-        classify_panel(((int)blockIdx.x - stage_blocks) * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows,
-                       rowptr, colidx, max_row_len, min_density, info, 0, epoch);
+        classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
+                       max_row_len, min_density, info, 0, epoch);
     }
 }
 // column span of a classified panel (0 for an empty one)
@@ -3176,7 +3182,7 @@ static inline unsigned capped_grid(int64_t work_items, int per_block)
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
                                     double *Bt, int64_t ldbt)
 {
-    dim3 grid((unsigned)((cols + 1 + 63) / 64), (unsigned)((ldbt + 63) / 64));
+    dim3 grid((unsigned)((cols + 1 + STAGE_K - 1) / STAGE_K), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt);
     return hipGetLastError();
 }
@@ -3261,7 +3267,7 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     int info_rows = 0, g = 2;
     gen6_plan(rows, info_rows, g);
     const int np = (rows + info_rows - 1) / info_rows;
-    const int stage_blocks = (int)((cols + 1 + 63) / 64);
+    const int stage_blocks = (int)((cols + 1 + STAGE_K - 1) / STAGE_K);
     const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
     int2 *winfo = reinterpret_cast<int2 *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
