@@ -45,7 +45,7 @@ int main(int argc, char **argv)
         hipEventRecord(e0);
         CK(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C, rocsparse_datatype_f64_r, a.alg, rocsparse_spmm_stage_preprocess, &bytes, buf));
         hipEventRecord(e1); hipEventSynchronize(e1); float pre; hipEventElapsedTime(&pre, e0, e1);
-        for (int i = 0; i < 3; ++i) CK(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C, rocsparse_datatype_f64_r, a.alg, rocsparse_spmm_stage_compute, &bytes, buf));
+        for (int i = 0; i < 100; ++i) CK(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C, rocsparse_datatype_f64_r, a.alg, rocsparse_spmm_stage_compute, &bytes, buf));
         const int reps = 20;
         hipEventRecord(e0);
         for (int i = 0; i < reps; ++i) CK(rocsparse_spmm(handle, rocsparse_operation_none, rocsparse_operation_none, &alpha, A, B, &beta, C, rocsparse_datatype_f64_r, a.alg, rocsparse_spmm_stage_compute, &bytes, buf));
@@ -58,7 +58,7 @@ int main(int argc, char **argv)
         CK(rocsparse_spmv(handle, rocsparse_operation_none, &alpha, A, x, &beta, y, rocsparse_datatype_f64_r, rocsparse_spmv_alg_default, rocsparse_spmv_stage_buffer_size, &bytes, nullptr));
         CK(hipMalloc(&buf, bytes ? bytes : 8));
         CK(rocsparse_spmv(handle, rocsparse_operation_none, &alpha, A, x, &beta, y, rocsparse_datatype_f64_r, rocsparse_spmv_alg_default, rocsparse_spmv_stage_preprocess, &bytes, buf));
-        for (int i = 0; i < 3; ++i) CK(rocsparse_spmv(handle, rocsparse_operation_none, &alpha, A, x, &beta, y, rocsparse_datatype_f64_r, rocsparse_spmv_alg_default, rocsparse_spmv_stage_compute, &bytes, buf));
+        for (int i = 0; i < 500; ++i) CK(rocsparse_spmv(handle, rocsparse_operation_none, &alpha, A, x, &beta, y, rocsparse_datatype_f64_r, rocsparse_spmv_alg_default, rocsparse_spmv_stage_compute, &bytes, buf));
         const int reps = 50;
         hipEventRecord(e0);
         for (int i = 0; i < reps; ++i) CK(rocsparse_spmv(handle, rocsparse_operation_none, &alpha, A, x, &beta, y, rocsparse_datatype_f64_r, rocsparse_spmv_alg_default, rocsparse_spmv_stage_compute, &bytes, buf));
