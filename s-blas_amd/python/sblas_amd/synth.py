@@ -55,7 +55,7 @@ def nd24k_like(scale=1.0):
     return rows, banded(rows, 399, 2000)
 
 
-def queen_like(rows, seed=SEED, half_band=50000):
+def queen_like(rows, seed=SEED, half_band=50000, progress=None):
     """Stand-in for SuiteSparse Queen_4147 (M = 4 147 110, ~76 nnz/row, 3-D structural FEM): every row holds 20..30
     clusters of 3 consecutive columns (3 dofs per mesh node) at stencil-like offsets inside +-half_band, the diagonal
     cluster always present; ascending, duplicate-free.  `rows` scales the matrix (band is clipped to it)."""
@@ -79,6 +79,8 @@ def queen_like(rows, seed=SEED, half_band=50000):
             chunk.append(np.unique(c))
             rowptr[r + 1] = chunk[-1].size
         cols_list.extend(chunk)
+        if progress is not None:
+            progress(r1)
     np.cumsum(rowptr, out=rowptr)
     colidx = np.concatenate(cols_list).astype(np.int32)
     val = rng.random(colidx.size) * 2.0 - 1.0

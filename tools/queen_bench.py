@@ -10,7 +10,7 @@ import oracle_py as O
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dev = torch.device("cuda:0")
-t0 = time.time(); rp, ci, v = synth.queen_like(rows); print("generated %d rows, %d nnz in %.1f s" % (rows, len(ci), time.time() - t0), flush=True)
+t0 = time.time(); rp, ci, v = synth.queen_like(rows, progress=(lambda r: print("  generated %d rows" % r, flush=True) if r % (16 * 65536) == 0 else None)); print("generated %d rows, %d nnz in %.1f s" % (rows, len(ci), time.time() - t0), flush=True)
 d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 rowptr, colidx, val = d(rp), d(ci), d(v)
 Bh = torch.rand(rows * n, dtype=torch.float64, generator=torch.Generator().manual_seed(211))
