@@ -332,6 +332,7 @@ def main():
     # correctness guard on this rank's result: C = 1 + (warmup+steps) * A*B on 64 sampled rows vs the oracle
     total_steps = settled + args.warmup + args.steps + extra_steps
     check = None
+    failures = []                                   # result mismatches found on rank 0 (fatal, reported at the end)
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_py as O
@@ -342,7 +343,10 @@ def main():
         want = 1.0 + total_steps * ref.reshape(n, rows)[:, r0:r0 + 64]
         check = bool(np.allclose(got, want, rtol=1e-9, atol=1e-9))
         if not check and not os.environ.get("SBLAS_ABLATE"):   # (SBLAS_ABLATE: diagnostic builds compute garbage on purpose)
-            raise SystemExit("bench result does not match the oracle: max diff %g" % np.abs(got - want).max())
+            msg = "bench result does not match the oracle: max diff %g" % np.abs(got - want).max()
+            if world == 1:
+                raise SystemExit(msg)
+            failures.append(msg)                    # N > 1: leaving now would strand the other ranks in a collective
 
 
     flops_step = 2.0 * nnz * n                      # per GPU
@@ -377,133 +381,139 @@ def main():
 
     # ---- method 2 (row-block A + RCCL merge), informational, N total = ncols ---------------------------------
     if world > 1 and not args.no_method2:
-        part = S.partition_nnz(rp, world, rank)
-        lo, k = part["first_nnz"], part["nnz"]
-        rp_i, ci_i, v_i = d(part["rowptr"]), colidx[lo:lo + k].contiguous(), val[lo:lo + k].contiguous()
-        m_i = len(part["rowptr"]) - 1
-        gen0 = torch.Generator(device="cpu").manual_seed(211)
-        B2 = torch.rand(cols * n, dtype=torch.float64, generator=gen0).to(dev)     # replicated B
-        C2 = torch.ones(rows * n, dtype=torch.float64, device=dev)
-        Ccopy = torch.zeros(rows * n, dtype=torch.float64, device=dev)
-        e = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+        # informational: an exception here (raised on every rank alike) must not cost the method-1 line above
+        try:
+            part = S.partition_nnz(rp, world, rank)
+            lo, k = part["first_nnz"], part["nnz"]
+            rp_i, ci_i, v_i = d(part["rowptr"]), colidx[lo:lo + k].contiguous(), val[lo:lo + k].contiguous()
+            m_i = len(part["rowptr"]) - 1
+            gen0 = torch.Generator(device="cpu").manual_seed(211)
+            B2 = torch.rand(cols * n, dtype=torch.float64, generator=gen0).to(dev)     # replicated B
+            C2 = torch.ones(rows * n, dtype=torch.float64, device=dev)
+            Ccopy = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+            e = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
-        def step2(k=None):
-            Ccopy.zero_()                                     # spmm.h:182-183 (zero buffer), on device
-            if k is not None: e[k][0].record()
-            S.dense_to_rowmajor(cols, n, B2, cols, Bt)
-            S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 1.0, Ccopy, rows, c_offset=part["start_row"])
-            if k is not None: e[k][1].record()
-            if args.dist_backend == "nccl":
-                dist.all_reduce(Ccopy)                        # spmm.h:260-262, RCCL over xGMI
-            else:                                             # rehearsal: gloo on a host copy
-                h = Ccopy.cpu()
-                dist.all_reduce(h)
-                Ccopy.copy_(h)
-            if k is not None: e[k][2].record()
-            S.axpby(rows * n, 1.0, Ccopy, 1.0, C2)            # spmm.h:283 -> kernel.h:27-38
-            if k is not None: e[k][3].record()
+            def step2(k=None):
+                Ccopy.zero_()                                     # spmm.h:182-183 (zero buffer), on device
+                if k is not None: e[k][0].record()
+                S.dense_to_rowmajor(cols, n, B2, cols, Bt)
+                S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 1.0, Ccopy, rows, c_offset=part["start_row"])
+                if k is not None: e[k][1].record()
+                if args.dist_backend == "nccl":
+                    dist.all_reduce(Ccopy)                        # spmm.h:260-262, RCCL over xGMI
+                else:                                             # rehearsal: gloo on a host copy
+                    h = Ccopy.cpu()
+                    dist.all_reduce(h)
+                    Ccopy.copy_(h)
+                if k is not None: e[k][2].record()
+                S.axpby(rows * n, 1.0, Ccopy, 1.0, C2)            # spmm.h:283 -> kernel.h:27-38
+                if k is not None: e[k][3].record()
 
-        for _ in range(args.warmup):
-            step2()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step2(k)
-        torch.cuda.synchronize()
-        barrier()
-        el2 = time.perf_counter() - t0
-        t = torch.tensor([el2], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t.item())
-        # method-2 result check on rank 0: C2 = 1 + (warmup+steps) * A*B2 on 64 sampled rows
-        m2_ok = None
-        if rank == 0:
-            import oracle_py as O2
-            r0 = rows // 2
-            ref2 = np.zeros(rows * n)
-            O2.spmm_rows(r0, r0 + 64, rows, cols, n, rp, ci, v, B2.cpu().numpy(), ref2, 1.0, 0.0)
-            got2 = C2.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
-            want2 = 1.0 + (args.warmup + args.steps) * ref2.reshape(n, rows)[:, r0:r0 + 64]   # (method 2 has no settling phase)
-            m2_ok = bool(np.allclose(got2, want2, rtol=1e-9, atol=1e-9))
-            if not m2_ok:
-                raise SystemExit("method-2 bench result does not match the oracle: max diff %g" % np.abs(got2 - want2).max())
-        out["method2"] = {
-            "oracle_check": m2_ok,
-            "scaling": "strong", "n_total_cols": n, "gflops": round(flops_step * args.steps / el2 / 1e9, 2),
-            "ms_per_step": round(el2 / args.steps * 1e3, 5),
-            "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e])), 5),
-            "ms_allreduce": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e])), 5),
-            "ms_axpby": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e])), 5),
-            "allreduce_payload_bytes": rows * n * 8,
-            "note": "rank-0 stage times; merge = torch.distributed all_reduce (RCCL) on the full M x N buffer as spmm.h:260-262",
-        }
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step2(k)
+            torch.cuda.synchronize()
+            barrier()
+            el2 = time.perf_counter() - t0
+            t = torch.tensor([el2], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+            # method-2 result check on rank 0: C2 = 1 + (warmup+steps) * A*B2 on 64 sampled rows
+            m2_ok = None
+            if rank == 0:
+                import oracle_py as O2
+                r0 = rows // 2
+                ref2 = np.zeros(rows * n)
+                O2.spmm_rows(r0, r0 + 64, rows, cols, n, rp, ci, v, B2.cpu().numpy(), ref2, 1.0, 0.0)
+                got2 = C2.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
+                want2 = 1.0 + (args.warmup + args.steps) * ref2.reshape(n, rows)[:, r0:r0 + 64]   # (method 2 has no settling phase)
+                m2_ok = bool(np.allclose(got2, want2, rtol=1e-9, atol=1e-9))
+                if not m2_ok:
+                    failures.append("method-2 bench result does not match the oracle: max diff %g" % np.abs(got2 - want2).max())
+            out["method2"] = {
+                "oracle_check": m2_ok,
+                "scaling": "strong", "n_total_cols": n, "gflops": round(flops_step * args.steps / el2 / 1e9, 2),
+                "ms_per_step": round(el2 / args.steps * 1e3, 5),
+                "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e])), 5),
+                "ms_allreduce": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e])), 5),
+                "ms_axpby": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e])), 5),
+                "allreduce_payload_bytes": rows * n * 8,
+                "note": "rank-0 stage times; merge = torch.distributed all_reduce (RCCL) on the full M x N buffer as spmm.h:260-262",
+            }
 
-        # ---- method 2, fast merge: packed row blocks, all-gather, one scatter + alpha/beta pass ---------
-        parts = [S.partition_nnz(rp, world, q) for q in range(world)]
-        starts = [p_["start_row"] for p_ in parts]
-        nrows = [len(p_["rowptr"]) - 1 for p_ in parts]
-        maxblk = max(max(nrows), 1) * n
-        mine = torch.zeros(maxblk, dtype=torch.float64, device=dev)           # packed m_i x n block (+ padding)
-        allb = torch.zeros(world * maxblk, dtype=torch.float64, device=dev)
-        C3 = torch.ones(rows * n, dtype=torch.float64, device=dev)
-        e3 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+            # ---- method 2, fast merge: packed row blocks, all-gather, one scatter + alpha/beta pass ---------
+            parts = [S.partition_nnz(rp, world, q) for q in range(world)]
+            starts = [p_["start_row"] for p_ in parts]
+            nrows = [len(p_["rowptr"]) - 1 for p_ in parts]
+            maxblk = max(max(nrows), 1) * n
+            mine = torch.zeros(maxblk, dtype=torch.float64, device=dev)           # packed m_i x n block (+ padding)
+            allb = torch.zeros(world * maxblk, dtype=torch.float64, device=dev)
+            C3 = torch.ones(rows * n, dtype=torch.float64, device=dev)
+            e3 = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
 
-        def step3(k=None):
-            if k is not None: e3[k][0].record()
-            S.dense_to_rowmajor(cols, n, B2, cols, Bt)
-            if m_i > 0:
-                S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 0.0, mine, m_i)   # beta = 0: no zero fill
-            if k is not None: e3[k][1].record()
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(allb, mine)        # half the bytes of the all-reduce
-            else:                                              # rehearsal: gloo on host copies
-                hs = [torch.empty(maxblk, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(hs, mine.cpu())
-                allb.copy_(torch.cat(hs))
-            if k is not None: e3[k][2].record()
-            S.merge_rowblocks_local(rows, n, starts, nrows, [allb[q * maxblk:(q + 1) * maxblk] for q in range(world)],
-                                    1.0, 1.0, C3)
-            if k is not None: e3[k][3].record()
+            def step3(k=None):
+                if k is not None: e3[k][0].record()
+                S.dense_to_rowmajor(cols, n, B2, cols, Bt)
+                if m_i > 0:
+                    S.spmm_rowmajorB(m_i, cols, rp_i, ci_i, v_i, Bt, n, 1.0, 0.0, mine, m_i)   # beta = 0: no zero fill
+                if k is not None: e3[k][1].record()
+                if args.dist_backend == "nccl":
+                    dist.all_gather_into_tensor(allb, mine)        # half the bytes of the all-reduce
+                else:                                              # rehearsal: gloo on host copies
+                    hs = [torch.empty(maxblk, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(hs, mine.cpu())
+                    allb.copy_(torch.cat(hs))
+                if k is not None: e3[k][2].record()
+                S.merge_rowblocks_local(rows, n, starts, nrows, [allb[q * maxblk:(q + 1) * maxblk] for q in range(world)],
+                                        1.0, 1.0, C3)
+                if k is not None: e3[k][3].record()
 
-        for _ in range(args.warmup):
-            step3()
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step3(k)
-        torch.cuda.synchronize()
-        barrier()
-        el3 = time.perf_counter() - t0
-        t = torch.tensor([el3], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el3 = float(t.item())
-        m3_ok = None
-        if rank == 0:
-            got3 = C3.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
-            m3_ok = bool(np.allclose(got3, want2, rtol=1e-9, atol=1e-9))
-            if not m3_ok:
-                raise SystemExit("method-2 (row-block merge) bench result does not match the oracle: max diff %g" % np.abs(got3 - want2).max())
-        out["method2_rowblocks"] = {
-            "oracle_check": m3_ok, "scaling": "strong", "n_total_cols": n,
-            "gflops": round(flops_step * args.steps / el3 / 1e9, 2), "ms_per_step": round(el3 / args.steps * 1e3, 5),
-            "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e3])), 5),
-            "ms_allgather": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e3])), 5),
-            "ms_merge": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e3])), 5),
-            "allgather_payload_bytes_per_rank": maxblk * 8,
-            "note": "packed row blocks (beta = 0), torch.distributed all_gather_into_tensor (RCCL), "
-                    "sblas_hip_merge_rowblocks_local_f64; the C++ API does the same with RCCL send/recv",
-        }
+            for _ in range(args.warmup):
+                step3()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                step3(k)
+            torch.cuda.synchronize()
+            barrier()
+            el3 = time.perf_counter() - t0
+            t = torch.tensor([el3], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el3 = float(t.item())
+            m3_ok = None
+            if rank == 0:
+                got3 = C3.view(n, rows)[:, r0:r0 + 64].cpu().numpy()
+                m3_ok = bool(np.allclose(got3, want2, rtol=1e-9, atol=1e-9))
+                if not m3_ok:
+                    failures.append("method-2 (row-block merge) bench result does not match the oracle: max diff %g" % np.abs(got3 - want2).max())
+            out["method2_rowblocks"] = {
+                "oracle_check": m3_ok, "scaling": "strong", "n_total_cols": n,
+                "gflops": round(flops_step * args.steps / el3 / 1e9, 2), "ms_per_step": round(el3 / args.steps * 1e3, 5),
+                "ms_spmm": round(float(np.mean([x[0].elapsed_time(x[1]) for x in e3])), 5),
+                "ms_allgather": round(float(np.mean([x[1].elapsed_time(x[2]) for x in e3])), 5),
+                "ms_merge": round(float(np.mean([x[2].elapsed_time(x[3]) for x in e3])), 5),
+                "allgather_payload_bytes_per_rank": maxblk * 8,
+                "note": "packed row blocks (beta = 0), torch.distributed all_gather_into_tensor (RCCL), "
+                        "sblas_hip_merge_rowblocks_local_f64; the C++ API does the same with RCCL send/recv",
+            }
+        except Exception as ex:
+            out["method2_error"] = repr(ex)
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(rows, cols, n, rp, ci, v, Bh.numpy(), args.cpu_seconds)
     elif rank == 0:
         out["cpu_baseline"] = None   # reported at N=1 only
-    if rank == 0:
+    if rank == 0 and not failures:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failures:                                    # a wrong result is never reported as a measurement
+        raise SystemExit("; ".join(failures))
 
 
 if __name__ == "__main__":
