@@ -9,6 +9,7 @@
 //   spmm_direct_dpp_kernel<GROUPS> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
 //   spmm_direct_rows_kernel      direct panels of short-row matrices (< 32 per row): four rows per wave
 //   spmm_rowpanel_narrow_kernel  n <= 8 (sub-wave lane groups; 16 / 32 columns behind SBLAS_SPMM_MIN_LDBT=0)
+//   spmm_rows8_kernel            n <= 8 and rows of 96+ nonzeros on average: a wave per row, eight sums per lane
 //   spmm_window{,2,3,4,5}_kernel, spmm_rowpanel_kernel   earlier generations, selectable (SBLAS_SPMM_VARIANT) and
 //                                kept as regression cases of the parity suite
 // SpMV  y = alpha*A*x + beta*y
@@ -2614,6 +2615,78 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
+// SpMM with at most 8 columns (ldbt = 8) and LONG rows: "SpMV with eight right-hand sides".  The lane-group kernel
+// above walks a row's nonzeros serially in an 8-lane group (0.33 ms on the bench matrix whatever N <= 8 is -- method
+// 1 on eight GPUs hands every GPU 8 of 64 columns).  Here a wave owns a row, its 64 lanes stride through the
+// nonzeros (coalesced col_idx / val streams, four slices in flight), every lane reads the 64-byte Bt row of its
+// nonzero and keeps eight partial sums; the eight sums are folded across the wave by a halving exchange (4 + 2 + 1
+// shuffles, then three more: ten instead of 48) and lanes 0, 8, .., 56 write columns 0..7.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmm_rows8_kernel(int rows, int cols, const int *__restrict__ rowptr,
+                                                        const int *__restrict__ colidx,
+                                                        const double *__restrict__ val,
+                                                        const double *__restrict__ Bt, int n, double alpha,
+                                                        double beta, double *__restrict__ C, int64_t ldc)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int p0 = wave_uniform(rowptr[row]), p1 = wave_uniform(rowptr[row + 1]);
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0;
+    for (int p = p0 + lane; p < p1; p += 4 * WAVE) { // (a lane past the end reads the all-zero row Bt[cols])
+        int c[4];
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = p + u * WAVE;
+            c[u] = q < p1 ? colidx[q] : cols;
+            v[u] = q < p1 ? val[q] : 0.0;
+        }
+        double2 b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double2 *__restrict__ br = reinterpret_cast<const double2 *>(Bt + (int64_t)c[u] * 8);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) b[u][h] = br[h];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                a[2 * h] = fma(v[u], b[u][h].x, a[2 * h]);
+                a[2 * h + 1] = fma(v[u], b[u][h].y, a[2 * h + 1]);
+            }
+    }
+    // halving exchange: after the step with mask m a lane keeps the half of its sums selected by (lane & m)
+    double b4[4], b2[2], s;
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[j] = (hi ? a[j + 4] : a[j]) + __shfl_xor(hi ? a[j] : a[j + 4], 32, WAVE);
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b2[j] = (hi ? b4[j + 2] : b4[j]) + __shfl_xor(hi ? b4[j] : b4[j + 2], 16, WAVE);
+    }
+    {
+        const bool hi = lane & 8;
+        s = (hi ? b2[1] : b2[0]) + __shfl_xor(hi ? b2[0] : b2[1], 8, WAVE);
+    }
+    s += __shfl_xor(s, 4, WAVE);
+    s += __shfl_xor(s, 2, WAVE);
+    s += __shfl_xor(s, 1, WAVE);
+    const int j = lane >> 3; // column of this lane's sum: (lane & 32 ? 4 : 0) + (lane & 16 ? 2 : 0) + (lane & 8 ? 1 : 0)
+    if ((lane & 7) == 0 && j < n) {
+        double *dst = C + (int64_t)j * ldc + row;
+        const double r = alpha * s;
+        *dst = (beta == 0.0) ? r : fma(beta, *dst, r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // SpMV for short and medium rows (5..48 nonzeros per row on average), stream form.  The lanes-per-row kernel gives every row a lane group
 // of 4..32 lanes: a 5-nonzero row keeps 4 of 8 lanes busy for two trips, and the stencil-like matrices that have such
 // rows run at 2.6-3.3 TB/s.  Here a 256-thread block owns 256 consecutive rows, i.e. ONE contiguous run of nonzeros:
@@ -3450,8 +3523,14 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<16>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
                            val, Bt, n, alpha, beta, C, ldc);
     } else {
-        hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<8>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
-                           val, Bt, n, alpha, beta, C, ldc);
+        // n <= 8.  Long rows: a wave per row, eight sums per lane.  SBLAS_SPMM_VARIANT=direct keeps the lane-group kernel.
+        const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+        if (avg >= 96.0 && variant != SPMM_VARIANT_DIRECT)
+            hipLaunchKernelGGL(spmm_rows8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, cols, rowptr,
+                               colidx, val, Bt, n, alpha, beta, C, ldc);
+        else
+            hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<8>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx,
+                               val, Bt, n, alpha, beta, C, ldc);
     }
     return hipGetLastError();
 }

@@ -795,3 +795,33 @@ def test_spmm_and_spmv_inside_a_hip_graph(env, kind):
         torch.cuda.synchronize()
         assert close(C.cpu().numpy(), oracle.spmm(rows, rows, n, *A.h, Bh, np.zeros(rows * n), 2.0, 0.0)), (kind, rep)
         assert close(y.cpu().numpy(), oracle.spmv(rows, *A.h, xh, np.zeros(rows), 2.0, 0.0)), (kind, rep)
+
+
+@pytest.mark.parametrize("n", [1, 3, 8])
+@pytest.mark.parametrize("kind", ["banded", "ragged"])
+def test_spmm_up_to_eight_columns_long_rows(env, n, kind):
+    """N <= 8 with rows of 96+ nonzeros on average takes the wave-per-row kernel (eight sums per lane, halving
+    exchange): row counts that are not a multiple of 4, empty rows, one row of 3000, lengths that are not a multiple of
+    64 or 256; an Inf in a row of B that no nonzero refers to must not leak in through the padding lanes."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    if kind == "banded":
+        rows = 2999
+        rp, ci, v = synth.banded(rows, 150, 700)
+        cols = rows
+    else:
+        rows, cols = 1237, 4000
+        rp, ci, v = synth.random_csr(rows, cols, 130, seed=7, empty_every=9, long_row=(33, 3000))
+    A = Dev(torch, dev, rp, ci, v, cols)
+    rng = np.random.default_rng(n)
+    Bh = rng.standard_normal(cols * n)
+    unused = np.setdiff1d(np.arange(cols), ci)
+    if unused.size:
+        Bh.reshape(n, cols)[:, unused[0]] = np.inf
+    Ch = rng.standard_normal(rows * n)
+    ws = torch.empty(max(sblas.spmm_workspace_bytes(rows, cols, len(ci), n) // 8, 1), dtype=torch.float64, device=dev)
+    for alpha, beta in ((1.0, 1.0), (-2.0, 0.0), (0.5, 3.0)):
+        B, C = torch.from_numpy(Bh).to(dev), torch.from_numpy(Ch.copy()).to(dev)
+        sblas.spmm(rows, cols, A.rowptr, A.colidx, A.val, B, cols, n, alpha, beta, C, rows, ws)
+        ref = oracle.spmm(rows, cols, n, *A.h, Bh, Ch.copy(), alpha, beta)
+        assert close(C.cpu().numpy(), ref), (n, kind, alpha, beta)
