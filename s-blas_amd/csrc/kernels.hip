@@ -9,7 +9,7 @@
 //   spmm_direct_dpp_kernel<GROUPS> DEFAULT for all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
 //   spmm_direct_rows_kernel      direct panels of short-row matrices (< 32 per row): four rows per wave
 //   spmm_rowpanel_narrow_kernel  n <= 8 (sub-wave lane groups; 16 / 32 columns behind SBLAS_SPMM_MIN_LDBT=0)
-//   spmm_rows8_kernel            n <= 8 and rows of 96+ nonzeros on average: a wave per row, eight sums per lane
+//   spmm_rows8_kernel            n <= 8 and rows of 256+ nonzeros on average: a wave per row, eight sums per lane
 //   spmm_window{,2,3,4,5}_kernel, spmm_rowpanel_kernel   earlier generations, selectable (SBLAS_SPMM_VARIANT) and
 //                                kept as regression cases of the parity suite
 // SpMV  y = alpha*A*x + beta*y
@@ -2615,7 +2615,7 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// SpMM with at most 8 columns (ldbt = 8) and LONG rows: "SpMV with eight right-hand sides".  The lane-group kernel
+// SpMM with at most 8 columns (ldbt = 8) and LONG rows (256+ on average): "SpMV with eight right-hand sides".  The lane-group kernel
 // above walks a row's nonzeros serially in an 8-lane group (0.33 ms on the bench matrix whatever N <= 8 is -- method
 // 1 on eight GPUs hands every GPU 8 of 64 columns).  Here a wave owns a row, its 64 lanes stride through the
 // nonzeros (coalesced col_idx / val streams, four slices in flight), every lane reads the 64-byte Bt row of its
@@ -3525,7 +3525,10 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
     } else {
         // n <= 8.  Long rows: a wave per row, eight sums per lane.  SBLAS_SPMM_VARIANT=direct keeps the lane-group kernel.
         const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
-        if (avg >= 96.0 && variant != SPMM_VARIANT_DIRECT)
+        const char *ra = getenv("SBLAS_ROWS8_MIN_AVG"); /* experiments: row length from which a wave owns a row */
+        // (banded-random rows, band +-20000, 600 k rows, N = 8: 64 / 128 / 200 / 300 per row: the lane groups win by
+        //  25 / 30 / 2 / 0 %; bench matrix, 399 per row, band +-2000: the wave per row wins by 20 % -- tools/rows8_threshold.py)
+        if (avg >= (ra ? atof(ra) : 256.0) && variant != SPMM_VARIANT_DIRECT)
             hipLaunchKernelGGL(spmm_rows8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, cols, rowptr,
                                colidx, val, Bt, n, alpha, beta, C, ldc);
         else

@@ -799,12 +799,13 @@ def test_spmm_and_spmv_inside_a_hip_graph(env, kind):
 
 @pytest.mark.parametrize("n", [1, 3, 8])
 @pytest.mark.parametrize("kind", ["banded", "ragged"])
-def test_spmm_up_to_eight_columns_long_rows(env, n, kind):
-    """N <= 8 with rows of 96+ nonzeros on average takes the wave-per-row kernel (eight sums per lane, halving
-    exchange): row counts that are not a multiple of 4, empty rows, one row of 3000, lengths that are not a multiple of
+def test_spmm_up_to_eight_columns_long_rows(env, monkeypatch, n, kind):
+    """N <= 8 with long rows takes the wave-per-row kernel (eight sums per lane, halving exchange) from 256 nonzeros
+    per row on average; the test moves the switch-over down with SBLAS_ROWS8_MIN_AVG.  Row counts that are not a multiple of 4, empty rows, one row of 3000, lengths that are not a multiple of
     64 or 256; an Inf in a row of B that no nonzero refers to must not leak in through the padding lanes."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
+    monkeypatch.setenv("SBLAS_ROWS8_MIN_AVG", "96")
     if kind == "banded":
         rows = 2999
         rp, ci, v = synth.banded(rows, 150, 700)
