@@ -3597,14 +3597,21 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     // long rows: x window in LDS (bench matrix: 70-73 us vs 82-85 us for the lanes-per-row kernel); a block whose
     // rows span more than the LDS window degrades to global gathers by itself.  SBLAS_SPMV_VARIANT=plain keeps the
     // lanes-per-row kernel for A/B runs.
+    // slices in flight per row: ~1.3-1.5 x the row length in 64-lane slices (600 k banded rows of 100 / 130 / 160 /
+    // 200 / 260, band +-2000: S = 2 / 3 / 3 / 4 / 7 take 273 / 307 / 315 / 360 / 433 us against 329 / 337 / 345 / 360 /
+    // 451 us with S = 4 throughout; the same order on a +-20000 band, tools/spmv_rowlen_sweep.py)
     if (avg > 96.0 && (!sv || !*sv || !strcmp(sv, "auto"))) {
-        if (avg <= 200.0) SBLAS_SPMV_LDS(1, 4);
+        if (avg <= 115.0) SBLAS_SPMV_LDS(1, 2);
+        if (avg <= 180.0) SBLAS_SPMV_LDS(1, 3);
+        if (avg <= 230.0) SBLAS_SPMV_LDS(1, 4);
         SBLAS_SPMV_LDS(1, 7);
     }
     if (avg > 96.0 && sv && !strcmp(sv, "lds")) SBLAS_SPMV_LDS(1, 7);
     if (avg > 96.0 && sv && !strcmp(sv, "lds2")) SBLAS_SPMV_LDS(2, 7);
     if (avg > 96.0 && sv && !strcmp(sv, "lds2s4")) SBLAS_SPMV_LDS(2, 4);
     if (avg > 96.0 && sv && !strcmp(sv, "lds1s4")) SBLAS_SPMV_LDS(1, 4);
+    if (avg > 96.0 && sv && !strcmp(sv, "lds1s2")) SBLAS_SPMV_LDS(1, 2);
+    if (avg > 96.0 && sv && !strcmp(sv, "lds1s3")) SBLAS_SPMV_LDS(1, 3);
 #define SBLAS_SPMV_SEG(RV, SV)                                                                                       \
     do {                                                                                                             \
         hipLaunchKernelGGL((spmv_csr_seg_kernel<RV, SV>), dim3((unsigned)((rows + 4 * RV - 1) / (4 * RV))), dim3(256), \

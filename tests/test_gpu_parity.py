@@ -586,7 +586,7 @@ def spmv_variant_env():
         os.environ["SBLAS_SPMV_VARIANT"] = old
 
 
-@pytest.mark.parametrize("variant", ["plain", "burst", "window", "flat2", "flat4", "flat8", "lds", "lds2", "lds2s4", "seg2", "seg3", "seg4", "seg8"])
+@pytest.mark.parametrize("variant", ["plain", "burst", "window", "flat2", "flat4", "flat8", "lds", "lds2", "lds2s4", "lds1s2", "lds1s3", "auto", "seg2", "seg3", "seg4", "seg8"])
 @pytest.mark.parametrize("kind", ["banded", "unsorted", "wide_span", "outliers"])
 def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
     """Long rows (the 64-lanes-per-row instantiation, unrolled four slices deep): banded, shuffled, very wide spans

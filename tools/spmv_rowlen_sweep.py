@@ -1,4 +1,4 @@
-"""SpMV variants by row length (banded synthetic, 600k rows, band +-20000): us per call for each variant."""
+"""SpMV variants by row length (banded synthetic, 600k rows, band +-20000 or argv[3]): us per call for each variant."""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "s-blas_amd", "python"))
@@ -7,7 +7,7 @@ from sblas_amd import synth
 dev = torch.device("cuda:0")
 rows = 600000
 for per in [int(a) for a in sys.argv[1].split(",")]:
-    rp, ci, v = synth.banded(rows, per, 20000)
+    rp, ci, v = synth.banded(rows, per, int(sys.argv[3]) if len(sys.argv) > 3 else 20000)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rowptr, colidx, val = d(rp), d(ci), d(v)
     x, y = torch.ones(rows, dtype=torch.float64, device=dev), torch.zeros(rows, dtype=torch.float64, device=dev)
