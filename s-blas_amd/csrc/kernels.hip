@@ -3610,7 +3610,7 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     if (avg > 96.0 && sv && !strcmp(sv, "lds2")) SBLAS_SPMV_LDS(2, 7);
     if (avg > 96.0 && sv && !strcmp(sv, "lds2s4")) SBLAS_SPMV_LDS(2, 4);
     if (avg > 96.0 && sv && !strcmp(sv, "lds1s4")) SBLAS_SPMV_LDS(1, 4);
-    if (avg > 96.0 && sv && !strcmp(sv, "lds1s2")) SBLAS_SPMV_LDS(1, 2);
+    if (avg > 32.0 && sv && !strcmp(sv, "lds1s2")) SBLAS_SPMV_LDS(1, 2);
     if (avg > 96.0 && sv && !strcmp(sv, "lds1s3")) SBLAS_SPMV_LDS(1, 3);
 #define SBLAS_SPMV_SEG(RV, SV)                                                                                       \
     do {                                                                                                             \
