@@ -283,6 +283,13 @@ def main():
         S.spmm(rows, cols, rowptr, colidx, val, B, cols, n, 1.0, 1.0, C, rows, Bt)
 
     settled = 0 if args.no_settle else settle(torch, step)
+    if dist is not None and not args.no_settle:
+        # ranks settle after different step counts (140-220): line them up, then 40 more steps each, so that no rank
+        # sits idle (and drops its clocks again) for tens of milliseconds in front of the timed region
+        barrier()
+        for _ in range(40):
+            step()
+        settled += 40
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
