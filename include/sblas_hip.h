@@ -82,9 +82,10 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
  * took the LDS-windowed path [0], the direct path because they are too sparse over their column span [1], or were
  * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2].  out[3] = 0. */
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
-/* Diagnostics: per-phase shader-cycle sums written by the windowed kernel when SBLAS_ABLATE has bit 2 set
- * (a diagnostic mode; see g_prof in kernels.hip for the slots). */
-int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset);
+/* The library reads its experiment switches (SBLAS_SPMM_VARIANT, SBLAS_SPMV_VARIANT, ...; none changes a result) from
+ * the environment once, at the first launch.  A process that changes them afterwards (the test-suite does) calls this
+ * to have them read again. */
+int sblas_hip_debug_reload_env(void);
 /* Diagnostics for per-kernel timing (bench.py's roofline object): while enabled, the SpMM launcher brackets the
  * dominant stage-2 kernel (the LDS-windowed one) with two HIP events
  * on the launch stream; ..._last_kernel_ms waits for the second event of the most recent launch on the current device

@@ -30,26 +30,7 @@ struct DeviceScope {
     }
 };
 
-// SBLAS_SPMM_VARIANT=direct|win32|win64|win128 pins the stage-2 kernel (A/B runs, tests); default auto.
-inline int spmm_variant()
-{
-    const char *e = getenv("SBLAS_SPMM_VARIANT");
-    if (!e || !*e) return sblas::SPMM_VARIANT_AUTO;
-    if (!strcmp(e, "direct")) return sblas::SPMM_VARIANT_DIRECT;
-    if (!strcmp(e, "dpp")) return sblas::SPMM_VARIANT_DIRECT_DPP;
-    if (!strcmp(e, "rows")) return sblas::SPMM_VARIANT_DIRECT_ROWS;
-    if (!strcmp(e, "win2")) return sblas::SPMM_VARIANT_WINDOW2;
-    if (!strcmp(e, "win3")) return sblas::SPMM_VARIANT_WINDOW3;
-    if (!strcmp(e, "win4")) return sblas::SPMM_VARIANT_WINDOW4;
-    if (!strcmp(e, "win5")) return sblas::SPMM_VARIANT_WINDOW5;
-    if (!strcmp(e, "win6")) return sblas::SPMM_VARIANT_WINDOW6;
-    if (!strcmp(e, "win32")) return sblas::SPMM_VARIANT_WINDOW_R32;
-    if (!strcmp(e, "win64")) return sblas::SPMM_VARIANT_WINDOW_R64;
-    if (!strcmp(e, "win128")) return sblas::SPMM_VARIANT_WINDOW_R128;
-    if (!strcmp(e, "win64w64")) return sblas::SPMM_VARIANT_WINDOW_R64W64;
-    if (!strcmp(e, "win32w128")) return sblas::SPMM_VARIANT_WINDOW_R32W128;
-    return sblas::SPMM_VARIANT_AUTO;
-}
+inline int spmm_variant() { return sblas::options().spmm_variant; }
 
 inline bool csr_args_ok(int64_t rows, int64_t cols, int64_t nnz, const void *rowptr, const void *colidx,
                         const void *val)
@@ -107,23 +88,14 @@ int64_t sblas_hip_spmm_ldbt(int64_t n)
     // direct kernel reads only the first 32 columns of a Bt row (four nonzeros per instruction; Queen-like rows,
     // N = 16 / 32: 0.45 / 0.46 ms against 0.42 / 0.78 ms).  SBLAS_SPMM_MIN_LDBT=0 restores the 16- and 32-column
     // kernels (tests, A/B runs).
-    const char *me = getenv("SBLAS_SPMM_MIN_LDBT");
-    return ldbt_pick(n, me && atoi(me) < 64);
+    return ldbt_pick(n, sblas::options().min_ldbt < 64);
 }
 static bool ldbt_ok(int64_t ldbt, int64_t n) { return ldbt == ldbt_pick(n, false) || ldbt == ldbt_pick(n, true); }
 
 // The kernels address Bt with 32-bit byte offsets, so one stage-2 launch can cover at most 4 GiB of Bt.  The
 // top-level call therefore walks the dense columns in chunks of `w` columns with (cols+1)*ldbt(w)*8 <= 4 GiB
 // (Queen_4147 with N = 256: two chunks of 128).  SBLAS_SPMM_MAX_BT_BYTES lowers the limit (tests).
-static uint64_t bt_byte_limit()
-{
-    const char *e = getenv("SBLAS_SPMM_MAX_BT_BYTES");
-    if (e && *e) {
-        const unsigned long long v = strtoull(e, nullptr, 10);
-        if (v >= 4096 && v < 0xffffffffull) return v;
-    }
-    return 0xffffffffull;
-}
+static uint64_t bt_byte_limit() { return sblas::options().max_bt_bytes; }
 
 static int64_t spmm_chunk_cols(int64_t cols, int64_t n)
 {
@@ -167,6 +139,16 @@ int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t
                : SBLAS_E_HIP;
 }
 
+// A has no nonzeros (cols == 0 or nnz == 0): C = beta * C, nothing else.  Neither the staging copy nor the panel
+// verdicts behind it are touched, so a NULL / empty workspace is fine here.
+static int scale_only(int dev, void *stream, int64_t rows, int64_t n, double beta, double *C, int64_t ldc)
+{
+    if (beta == 1.0) return SBLAS_OK;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_scale((hipStream_t)stream, rows, n, beta, C, ldc) == hipSuccess ? SBLAS_OK : SBLAS_E_HIP;
+}
+
 static int spmm_staged(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
                        const int32_t *colidx, const double *val, const double *Bt, int64_t ldbt, int64_t n,
                        double alpha, double beta, double *C, int64_t ldc, int pre_epoch)
@@ -175,7 +157,8 @@ static int spmm_staged(int dev, void *stream, int64_t rows, int64_t cols, int64_
     if (rows == 0 || n == 0) return SBLAS_OK;
     if (!C || ldc < rows || n > INT_MAX) return SBLAS_E_INVALID;
     if (!ldbt_ok(ldbt, n)) return SBLAS_E_INVALID;
-    if (cols > 0 && !Bt) return SBLAS_E_INVALID;
+    if (cols == 0 || nnz == 0) return scale_only(dev, stream, rows, n, beta, C, ldc); // A*B = 0: no kernel reads Bt
+    if (!Bt) return SBLAS_E_INVALID;
     // the kernels address Bt with 32-bit element offsets (row * ldbt + column)
     if (ldbt >= 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_E_INVALID; // 32-bit byte offsets
     DeviceScope scope(dev);
@@ -204,6 +187,7 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (rows == 0 || n == 0) return SBLAS_OK;
     if (!C || ldc < rows) return SBLAS_E_INVALID;
     if (cols > 0 && (!B || ldb < cols)) return SBLAS_E_INVALID;
+    if (cols == 0 || nnz == 0) return scale_only(dev, stream, rows, n, beta, C, ldc);
     const size_t need = sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
     double *Bt = static_cast<double *>(workspace);
@@ -212,7 +196,7 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
         const int64_t ldbt = chunk_ldbt(cols, n, nj);
         int rc, pre_epoch = 0;
-        if (spmm_variant() == sblas::SPMM_VARIANT_AUTO && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
+        if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
             ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
             DeviceScope scope(dev);
@@ -231,12 +215,9 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     return SBLAS_OK;
 }
 
-int sblas_hip_debug_spmm_cycle_stamps(uint64_t out[16], int reset)
+int sblas_hip_debug_reload_env(void)
 {
-    if (!out) return SBLAS_E_INVALID;
-    unsigned long long tmp[16];
-    if (sblas::prof_stats(tmp, reset != 0) != hipSuccess) return SBLAS_E_HIP;
-    for (int i = 0; i < 16; ++i) out[i] = tmp[i];
+    sblas::options_reload();
     return SBLAS_OK;
 }
 

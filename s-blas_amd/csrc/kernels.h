@@ -1,4 +1,4 @@
-// kernels.h -- internal launcher interface between kernels.hip and the C-ABI layer (capi.hip).
+// kernels.h -- internal launcher interface between the kernel translation units and the C-ABI layer (capi.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,22 +10,44 @@ struct ReplicaPtrs {
     double *p[MAX_REPLICAS];
 };
 
+// SpMM stage-2 selection (SBLAS_SPMM_VARIANT, experiments and tests only).  AUTO = panel classifier, then the
+// LDS-tiled / MFMA kernels on the panels that qualify and a direct kernel on the rest.
+enum {
+    SPMM_VARIANT_AUTO = 0,
+    SPMM_VARIANT_DIRECT_DPP = 1,  // "dpp":   every panel through the row-per-wave direct kernel
+    SPMM_VARIANT_DIRECT_ROWS = 2, // "rows":  every panel through the four-rows-per-wave direct kernel
+    SPMM_VARIANT_LANES = 3,       // "lanes": n <= 8 keeps the lane-group kernel whatever the row length (else AUTO)
+    SPMM_VARIANT_GRID2D = 4,      // "grid2d": every direct panel through the 2-D (row block x column block) kernel
+    SPMM_VARIANT_MFMA = 5,        // "mfma":  LDS-tiled panels through the MFMA kernel whatever their block density
+    SPMM_VARIANT_NO_MFMA = 6,     // "nomfma": never the MFMA kernel
+};
+constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (one int2 of workspace per panel)
+
+// Experiment / test switches, read from the environment once (kernels.hip); options_reload() re-reads them.
+struct Options {
+    int spmm_variant = SPMM_VARIANT_AUTO;
+    char spmv_variant[16] = {0};          // "" = auto
+    int min_ldbt = 64;                    // SBLAS_SPMM_MIN_LDBT: < 64 re-enables the 16- / 32-column staging tiers
+    unsigned long long max_bt_bytes = 0xffffffffull; // SBLAS_SPMM_MAX_BT_BYTES (tests of the column-chunk loop)
+    int direct_lds = -1;                  // SBLAS_DIRECT_LDS
+    int direct_map = -1;                  // SBLAS_DIRECT_MAP: 1 interleave, 0 contiguous, -1 by span
+    double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
+    int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
+    int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE
+};
+const Options &options();
+void options_reload();
+void raise_dynamic_lds(const void *fn, size_t bytes);
+
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
                                     double *Bt, int64_t ldbt);
-// SpMM stage-2 variants (wide form).  AUTO = the fastest measured one (round 1: panel classifier + WINDOW4 + DIRECT_DPP
-// for the panels the classifier rejects); the other LDS-windowed
-// row-panel x B-tile kernels (with their per-panel fallback) and the readlane kernel stay selectable for A/B runs
-// and tests through SBLAS_SPMM_VARIANT.
-enum { SPMM_VARIANT_AUTO = 0, SPMM_VARIANT_DIRECT = 1, SPMM_VARIANT_WINDOW_R32 = 2, SPMM_VARIANT_WINDOW_R64 = 3,
-       SPMM_VARIANT_WINDOW_R128 = 4, SPMM_VARIANT_WINDOW_R64W64 = 5, SPMM_VARIANT_WINDOW_R32W128 = 6, SPMM_VARIANT_DIRECT_DPP = 7, SPMM_VARIANT_WINDOW2 = 8, SPMM_VARIANT_WINDOW3 = 9, SPMM_VARIANT_WINDOW4 = 10, SPMM_VARIANT_WINDOW5 = 11, SPMM_VARIANT_WINDOW6 = 12, SPMM_VARIANT_DIRECT_ROWS = 13 };
-constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (one int2 of workspace per panel; generation 6: 32)
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
                                 double beta, double *C, int64_t ldc, int variant, int pre_epoch = 0);
 hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
                                  int64_t ldbt, int rows, const int *rowptr, const int *colidx, int *epoch_out);
+hipError_t launch_scale(hipStream_t s, int64_t rows, int64_t n, double beta, double *C, int64_t ldc);
 hipError_t panel_stats(unsigned long long out[4], bool reset);
-hipError_t prof_stats(unsigned long long out[16], bool reset);
 hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                        const double *val, const double *x, double alpha, double beta, double *y);
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y);

@@ -1,0 +1,437 @@
+// spmv_kernels.hip -- hand-written gfx950 (wave64) CSR SpMV kernels  y = alpha*A*x + beta*y  (replaces cusparseSpMV,
+// spmv.h:104-106).  The launcher at the end picks the kernel by row-length class.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "kernels.h"
+
+namespace sblas {
+
+constexpr int WAVE = 64;
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------------------------
+// SpMV: LPR lanes per row (a power of two, 4..64), 256/LPR rows per workgroup.  The lanes of a
+// group stride through the row's nonzeros (coalesced col_idx / val streams, x gathered through
+// L2), then the partial sums are folded with xor-shuffles inside the wave -- the wave64 successor of
+// the reference's unused sum_32_shfl (utility.h:241-246).
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__restrict__ rowptr,
+                                                      const int *__restrict__ colidx,
+                                                      const double *__restrict__ val,
+                                                      const double *__restrict__ x, double alpha, double beta,
+                                                      double *__restrict__ y)
+{
+    constexpr int ROWS_PER_BLOCK = 256 / LPR;
+    const int l = threadIdx.x % LPR;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / LPR;
+    double s0 = 0.0, s1 = 0.0;
+    if (row < rows) {
+        const int p1 = rowptr[row + 1];
+        int p = rowptr[row] + l;
+        // two slices per trip (four gave fewer resident waves and ran 20 % slower)
+        for (; p + LPR < p1; p += 2 * LPR) {
+            const int c0 = colidx[p], c1 = colidx[p + LPR];
+            const double a0 = val[p], a1 = val[p + LPR];
+            s0 = fma(a0, x[c0], s0);
+            s1 = fma(a1, x[c1], s1);
+        }
+        if (p < p1) s0 = fma(val[p], x[colidx[p]], s0);
+    }
+    double s = s0 + s1;
+#pragma unroll
+    for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, WAVE);
+    if (row < rows && l == 0) {
+        const double r = alpha * s;
+        y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for short and medium rows (5..48 nonzeros per row on average), stream form.  The lanes-per-row kernel gives every row a lane group
+// of 4..32 lanes: a 5-nonzero row keeps 4 of 8 lanes busy for two trips, and the stencil-like matrices that have such
+// rows run at 2.6-3.3 TB/s.  Here a 256-thread block owns 256 consecutive rows, i.e. ONE contiguous run of nonzeros:
+// all threads stream it (thread t takes nonzeros t, t + 256, ...; every lane busy, fully coalesced), park the
+// products in LDS, and thread r then adds up the products of row r in CSR order.  A block whose rows hold more than
+// the LDS can take (longer rows among the short ones) takes its rows in several runs.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_ROWS = 256;
+constexpr int ST_CAP = 6144; // products per block (48 KiB + skew): three blocks per CU
+__device__ __forceinline__ int st_skew(int q) { return q + (q >> 5); } // rows of equal length: spread the LDS banks
+__global__ __launch_bounds__(ST_ROWS) void spmv_csr_stream_kernel(int rows, const int *__restrict__ rowptr,
+                                                                 const int *__restrict__ colidx,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ x, double alpha, double beta,
+                                                                 double *__restrict__ y)
+{
+    __shared__ double prod[ST_CAP + ST_CAP / 32 + 1];
+    __shared__ int sp[ST_ROWS + 1];
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * ST_ROWS;
+    const int nr = min(ST_ROWS, rows - row0);
+    if (tid < nr) sp[tid] = rowptr[row0 + tid];
+    if (tid == 0) sp[nr] = rowptr[row0 + nr];
+    __syncthreads();
+    __shared__ double wsum[ST_ROWS / 64];
+    // The block's rows are taken in runs whose nonzeros fit the LDS: normally one run (all 256 rows); a block with
+    // longer rows takes several, and a single row beyond the capacity is summed by the whole block.
+    for (int r0 = 0; r0 < nr;) {
+        const int base = sp[r0];
+        int r1 = nr;
+        if (sp[nr] - base > ST_CAP) { // largest r1 with sp[r1] - base <= ST_CAP (block-uniform: every thread searches)
+            int lo = r0, hi = nr;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sp[mid] - base <= ST_CAP) lo = mid; else hi = mid - 1;
+            }
+            r1 = lo;
+        }
+        if (r1 == r0) { // one row longer than the LDS capacity
+            double sum = 0.0;
+            for (int p = base + tid; p < sp[r0 + 1]; p += ST_ROWS) sum = fma(val[p], x[colidx[p]], sum);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+            if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < ST_ROWS / 64; ++w) t += wsum[w];
+                const double res = alpha * t;
+                y[row0 + r0] = (beta == 0.0) ? res : fma(beta, y[row0 + r0], res);
+            }
+            __syncthreads();
+            r0 += 1;
+            continue;
+        }
+        const int total = sp[r1] - base;
+        // UN nonzeros per thread in flight (clamped indices instead of predicates: no waits between the loads)
+        constexpr int UN = 8;
+        const int lastp = max(total - 1, 0);
+        for (int p = tid; p < total; p += UN * ST_ROWS) {
+            int c[UN];
+            double a[UN], xv[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int q = min(p + u * ST_ROWS, lastp);
+                c[u] = colidx[base + q];
+                a[u] = val[base + q];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) xv[u] = x[c[u]];
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (p + u * ST_ROWS < total) prod[st_skew(p + u * ST_ROWS)] = a[u] * xv[u];
+        }
+        __syncthreads();
+        if (tid >= r0 && tid < r1) {
+            double sum = 0.0;
+            for (int q = sp[tid] - base, e = sp[tid + 1] - base; q < e; ++q) sum += prod[st_skew(q)];
+            const double res = alpha * sum;
+            y[row0 + tid] = (beta == 0.0) ? res : fma(beta, y[row0 + tid], res);
+        }
+        if (r1 < nr) __syncthreads(); // prod is reused by the next run
+        r0 = r1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for medium rows (49..96 nonzeros), segmented form.  With one row per wave a 73-nonzero row (Queen_4147) fills
+// 57 % of two 64-lane slices and walks two dependent trips: 2.3 TB/s.  Here a wave owns R consecutive rows -- one
+// contiguous run of nonzeros -- and streams it in unpredicated slices of 64 (clamped indices, S slices in flight:
+// 91 % of the lanes busy for R = 4, S = 5 at 73 per row); every lane knows the row of its entry from the R + 1 row
+// pointers (wave-uniform after a readlane), products are accumulated per row and folded once at the end: the
+// wave-level segmented reduction of the north star.
+// ---------------------------------------------------------------------------------------------
+template <int R, int S>
+__global__ __launch_bounds__(256) void spmv_csr_seg_kernel(int rows, const int *__restrict__ rowptr,
+                                                          const int *__restrict__ colidx,
+                                                          const double *__restrict__ val,
+                                                          const double *__restrict__ x, double alpha, double beta,
+                                                          double *__restrict__ y)
+{
+    static_assert(R >= 1 && R <= 16, "row pointers are broadcast from the first R + 1 lanes");
+    const int lane = threadIdx.x & 63;
+    const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (r0 >= rows) return;
+    const int mine = rowptr[min(r0 + min(lane, R), rows)];
+    int b[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; ++i) b[i] = __builtin_amdgcn_readlane(mine, i);
+    const int p0 = b[0], p1 = b[R], last = p1 - 1;
+    double acc[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i] = 0.0;
+    for (int base = p0; base < p1; base += S * WAVE) {
+        int c[S];
+        double a[S], xv[S];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int p = min(base + u * WAVE + lane, last);
+            c[u] = colidx[p];
+            a[u] = val[p];
+        }
+#pragma unroll
+        for (int u = 0; u < S; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            const int idx = base + u * WAVE + lane;
+            const double prod = (idx <= last) ? a[u] * xv[u] : 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) acc[i] += (idx >= b[i] && idx < b[i + 1]) ? prod : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        double sum = acc[i];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+        if (lane == i && r0 + i < rows) {
+            const double res = alpha * sum;
+            y[r0 + i] = (beta == 0.0) ? res : fma(beta, y[r0 + i], res);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpMV for long rows, x window in LDS (second attempt).  Diagnostics on the plain kernel: the A stream alone runs at
+// 6.8 TB/s with the same row-per-wave shape (tools/stream_bench.hip), replacing the gather by a one-line read still
+// leaves 76 us -- what costs is the second, dependent vector-memory access per slice (address unit ~15 cycles per
+// instruction, more for a 40-line gather).  Here a 16-row block (one row per wave) fetches the x range its rows span
+// into LDS once and gathers from there; the stream loads of a row (up to 448 nonzeros) are issued right after its row
+// pointers, BEFORE the window is known, so the block-wide min/max, the window load and their three barriers hide
+// behind the HBM latency of the stream (the barriers are `s_barrier` without the vmcnt(0) of __syncthreads).
+// Columns outside the window (unsorted rows) are fetched from global memory lane by lane.
+// ---------------------------------------------------------------------------------------------
+constexpr int SPMV_LDS_ROWS = 16;   // = waves per block
+constexpr int SPMV_LDS_CAP = 5120;  // doubles (40 KiB): two blocks per CU
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RW, int S> // RW rows per wave (16 RW rows per block), S slices of 64 nonzeros fetched ahead per row
+__global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx,
+                                                           const double *__restrict__ val,
+                                                           const double *__restrict__ x, double alpha, double beta,
+                                                           double *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    __shared__ int sm_lo, sm_hi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = (blockIdx.x * SPMV_LDS_ROWS + wave) * RW;
+    if (tid == 0) {
+        sm_lo = 0x7fffffff;
+        sm_hi = -1;
+    }
+    int p0[RW], last[RW];
+    bool has[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        int a0 = 0, a1 = 0;
+        if (row0 + r < rows) {
+            a0 = wave_uniform(rowptr[row0 + r]);
+            a1 = wave_uniform(rowptr[row0 + r + 1]);
+        }
+        p0[r] = a0;
+        has[r] = a1 > a0;
+        last[r] = max(a1 - 1, a0);
+    }
+    // the two ends of every row first (lane 2r: first column of row r, lane 2r+1: its last column), then the first
+    // burst of the streams
+    int c[RW][S];
+    double a[RW][S];
+    int ce = 0;
+    bool ce_valid = false;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (has[r] && (lane >> 1) == r) {
+            ce = colidx[(lane & 1) ? last[r] : p0[r]];
+            ce_valid = true;
+        }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+        if (has[r]) {
+#pragma unroll
+            for (int u = 0; u < S; ++u) {
+                const int p = min(p0[r] + u * WAVE + lane, last[r]);
+                c[r][u] = colidx[p];
+                a[r][u] = val[p];
+            }
+        }
+    lds_barrier(); // sm_lo / sm_hi initialised
+    if (ce_valid) {
+        if (lane & 1) atomicMax(&sm_hi, ce);
+        else atomicMin(&sm_lo, ce);
+    }
+    lds_barrier();
+    int lo = sm_lo, hi = sm_hi;
+    if (lo > hi) {
+        lo = 0;
+        hi = -1;
+    }
+    lo = max(lo, 0);
+    hi = min(hi, cols - 1);
+    // a span that does not fit is not staged at all: every gather then goes to global memory, as in the plain kernel.
+    // The window starts at an even column so that it can be fetched by LDS-DMA in 16-byte pieces (x 16-byte aligned,
+    // the last pair inside x); otherwise eight bytes per thread through registers.
+    lo &= ~1;
+    const int wlen = (hi - lo + 1 <= SPMV_LDS_CAP) ? hi - lo + 1 : 0;
+    const int pairs = (wlen + 1) >> 1;
+    if (wlen > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && lo + 2 * pairs <= cols) {
+        const char *src = reinterpret_cast<const char *>(x + lo);
+        for (int p0 = wave * 64; p0 < pairs; p0 += 1024) { // (wave-uniform trip count)
+            const int pr = min(p0 + lane, pairs - 1);  // clamped lanes rewrite the last pair into the slack area
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)pr * 16),
+                                             (__attribute__((address_space(3))) void *)(xs + 2 * p0), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (wlen > 0) {
+        // the whole window in one burst of loads (clamped indices), then the stores
+        constexpr int PASSES = SPMV_LDS_CAP / 1024;
+        double t[PASSES];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) t[j] = x[lo + min(tid + 1024 * j, wlen - 1)];
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j)
+            if (tid + 1024 * j < wlen) xs[tid + 1024 * j] = t[j];
+    }
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int row = row0 + r;
+        if (row >= rows) break;
+        double s0 = 0.0, s1 = 0.0;
+        if (has[r]) {
+            for (int base = p0[r];;) {
+                double xv[S];
+                bool out = false;
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const bool live = base + u * WAVE + lane <= last[r];
+                    const unsigned rel = (unsigned)(c[r][u] - lo);
+                    const bool inw = rel < (unsigned)wlen;
+                    // never multiply by unstaged LDS (a block whose span is not staged has wlen = 0) nor, in a clamped
+                    // lane, by a staged Inf / NaN that belongs to another entry: dead lanes contribute exactly 0 * 0
+                    const double staged = xs[inw ? rel : 0u];
+                    xv[u] = (inw && live) ? staged : 0.0;
+                    out |= live && !inw;
+                }
+                if (__builtin_amdgcn_ballot_w64(out) != 0ull) { // columns outside the window (unsorted rows, wide spans)
+#pragma unroll
+                    for (int u = 0; u < S; ++u) {
+                        const bool live = base + u * WAVE + lane <= last[r];
+                        if (live && (unsigned)(c[r][u] - lo) >= (unsigned)wlen) xv[u] = x[c[r][u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const double av = (base + u * WAVE + lane <= last[r]) ? a[r][u] : 0.0;
+                    if (u & 1) s1 = fma(av, xv[u], s1);
+                    else s0 = fma(av, xv[u], s0);
+                }
+                base += S * WAVE;
+                if (base > last[r]) break;
+#pragma unroll
+                for (int u = 0; u < S; ++u) {
+                    const int p = min(base + u * WAVE + lane, last[r]);
+                    c[r][u] = colidx[p];
+                    a[r][u] = val[p];
+                }
+            }
+        }
+        double sum = s0 + s1;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+        if (lane == 0) {
+            const double res = alpha * sum;
+            y[row] = (beta == 0.0) ? res : fma(beta, y[row], res);
+        }
+    }
+}
+
+
+template <int LPR>
+static hipError_t spmv_go(hipStream_t s, int rows, const int *rowptr, const int *colidx, const double *val,
+                          const double *x, double alpha, double beta, double *y)
+{
+    constexpr int rpb = 256 / LPR;
+    hipLaunchKernelGGL(spmv_csr_kernel<LPR>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, s, rows,
+                       rowptr, colidx, val, x, alpha, beta, y);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
+                       const double *val, const double *x, double alpha, double beta, double *y)
+{
+    const double avg = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    const char *sv = options().spmv_variant; // "" = auto; anything else pins a kernel (A/B runs, tests)
+    const bool autosel = !*sv;
+    auto is = [&](const char *name) { return !strcmp(sv, name); };
+#define SBLAS_SPMV_LDS(RWV, SV)                                                                                      \
+    do {                                                                                                             \
+        raise_dynamic_lds((const void *)spmv_csr_lds_kernel<RWV, SV>, (SPMV_LDS_CAP + 128) * sizeof(double));        \
+        hipLaunchKernelGGL((spmv_csr_lds_kernel<RWV, SV>),                                                           \
+                           dim3((unsigned)((rows + SPMV_LDS_ROWS * RWV - 1) / (SPMV_LDS_ROWS * RWV))), dim3(1024),    \
+                           (SPMV_LDS_CAP + 128) * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha, beta, y); \
+        return hipGetLastError();                                                                                    \
+    } while (0)
+#define SBLAS_SPMV_SEG(RV, SV)                                                                                       \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((spmv_csr_seg_kernel<RV, SV>), dim3((unsigned)((rows + 4 * RV - 1) / (4 * RV))), dim3(256), \
+                           0, s, rows, rowptr, colidx, val, x, alpha, beta, y);                                      \
+        return hipGetLastError();                                                                                    \
+    } while (0)
+    if (autosel) {
+        // long rows: x window in LDS (bench matrix: 70-73 us vs 82-85 us for the lanes-per-row kernel); a block whose
+        // rows span more than the LDS window degrades to global gathers by itself.  Slices in flight per row: ~1.3-1.5 x
+        // the row length in 64-lane slices (600 k banded rows of 100 / 130 / 160 / 200 / 260, band +-2000: S = 2 / 3 / 3 /
+        // 4 / 7 take 273 / 307 / 315 / 360 / 433 us against 329 / 337 / 345 / 360 / 451 us with S = 4 throughout; the
+        // same order on a +-20000 band, tools/spmv_rowlen_sweep.py)
+        if (avg > 96.0) {
+            if (avg <= 115.0) SBLAS_SPMV_LDS(1, 2);
+            if (avg <= 180.0) SBLAS_SPMV_LDS(1, 3);
+            if (avg <= 230.0) SBLAS_SPMV_LDS(1, 4);
+            SBLAS_SPMV_LDS(1, 7);
+        }
+        // medium rows: R rows per wave, segmented (Queen-like rows, 73 per row: 232 us vs 395 us; banded synthetic rows
+        // of 36 / 72 / 90: 122 / 266 / 351 us vs 150 / 339 / 375 us for the lanes-per-row kernel)
+        if (avg > 48.0) SBLAS_SPMV_SEG(4, 5);
+        // short and medium rows (5 < avg <= 48): 256 rows per block streamed through LDS, in runs of up to 6144
+        // products (stencil-like rows of 7 / 13 / 27: 108 / 177 / 344 us vs 143 / 277 / 498 us for the lanes-per-row and
+        // segmented kernels; banded-random rows of 14 / 20 / 28 / 36 / 48: 46 / 62 / 85 / 116 / 161 vs 49 / 71 / 94 /
+        // 128 / 194).  Above 48 the segmented kernel stays (Queen-like rows of 69: 52 us vs 85 us for the stream form,
+        // which needs three runs per block there); at 5 and below the lanes-per-row kernel is as fast or faster.
+        if (avg > 5.0) {
+            hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0,
+                               s, rows, rowptr, colidx, val, x, alpha, beta, y);
+            return hipGetLastError();
+        }
+        return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    }
+    if (is("lds")) SBLAS_SPMV_LDS(1, 7);
+    if (is("lds2")) SBLAS_SPMV_LDS(2, 7);
+    if (is("lds1s2")) SBLAS_SPMV_LDS(1, 2);
+    if (is("lds1s3")) SBLAS_SPMV_LDS(1, 3);
+    if (is("lds1s4")) SBLAS_SPMV_LDS(1, 4);
+    if (is("seg4")) SBLAS_SPMV_SEG(4, 5);
+    if (is("seg3")) SBLAS_SPMV_SEG(3, 4);
+    if (is("seg8")) SBLAS_SPMV_SEG(8, 5);
+    if (is("seg2")) SBLAS_SPMV_SEG(2, 3);
+#undef SBLAS_SPMV_LDS
+#undef SBLAS_SPMV_SEG
+    if (is("stream")) {
+        hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0, s,
+                           rows, rowptr, colidx, val, x, alpha, beta, y);
+        return hipGetLastError();
+    }
+    // "plain" (and anything unknown): lanes per row by average length
+    if (avg <= 6.0) return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 12.0) return spmv_go<8>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 24.0) return spmv_go<16>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    if (avg <= 48.0) return spmv_go<32>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    return spmv_go<64>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
+}
+
+} // namespace sblas

@@ -157,7 +157,7 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         if (use_allreduce) {
             // zeroed partial-result buffer on the device (the reference uploads M*N zeros from the host);
             // A_i * B accumulated (alpha = beta = 1) at its row offset, ld = M
-            SAFE_ALOC_GPU(ccopy[i], cnt * sizeof(double));
+            ccopy[i] = (double *)sblas_rt::workspace(i, cnt * sizeof(double), sblas_rt::WS_PARTIAL);
             CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(double), (hipStream_t)streams[i]));
             sblas_rt::must_sblas(
                 sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
@@ -167,8 +167,8 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
                 "sblas_hip_spmm_csr_f64_i32");
         } else {
             // packed m_i x N block, beta = 0: nothing to clear
-            SAFE_ALOC_GPU(ccopy[i], std::max<size_t>((size_t)m_i * (size_t)N, 1) * sizeof(double));
-            SAFE_ALOC_GPU(gather[i], std::max<size_t>(all_blocks, 1) * sizeof(double));
+            ccopy[i] = (double *)sblas_rt::workspace(i, (size_t)m_i * (size_t)N * sizeof(double), sblas_rt::WS_PARTIAL);
+            gather[i] = (double *)sblas_rt::workspace(i, all_blocks * sizeof(double), sblas_rt::WS_GATHER);
             sblas_rt::must_sblas(
                 sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
                                            (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
@@ -205,8 +205,6 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         cout << "GPU-" << i << " NCCL Time: " << timers[i]->measure() << " ms." << std::endl;
         delete timers[i];
-        SAFE_FREE_GPU(ccopy[i]);
-        if (gather[i]) SAFE_FREE_GPU(gather[i]);
     }
     CUDA_CHECK_ERROR();
 }

@@ -69,11 +69,11 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
         streams[i] = sblas_rt::stream(i);
         const int64_t m_i = nrows[i];
         if (use_allreduce) {
-            SAFE_ALOC_GPU(ycopy[i], (size_t)M * sizeof(double));
+            ycopy[i] = (double *)sblas_rt::workspace(i, (size_t)M * sizeof(double), sblas_rt::WS_PARTIAL);
             CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(double), (hipStream_t)streams[i]));
         } else {
-            SAFE_ALOC_GPU(ycopy[i], std::max<size_t>((size_t)m_i, 1) * sizeof(double));
-            SAFE_ALOC_GPU(gather[i], std::max<size_t>(all_blocks, 1) * sizeof(double));
+            ycopy[i] = (double *)sblas_rt::workspace(i, (size_t)m_i * sizeof(double), sblas_rt::WS_PARTIAL);
+            gather[i] = (double *)sblas_rt::workspace(i, all_blocks * sizeof(double), sblas_rt::WS_GATHER);
         }
         sblas_rt::must_sblas(
             sblas_hip_spmv_csr_f64_i32(-1, streams[i], m_i, K, (int64_t)pA->nnz_gpu[i],
@@ -109,8 +109,6 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         cout << "GPU-" << i << " NCCL Time: " << timers[i]->measure() << " ms." << std::endl;
         delete timers[i];
-        SAFE_FREE_GPU(ycopy[i]);
-        if (gather[i]) SAFE_FREE_GPU(gather[i]);
     }
     CUDA_CHECK_ERROR();
 }

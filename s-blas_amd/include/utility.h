@@ -56,10 +56,12 @@ inline int physical_device(unsigned logical)
     return (int)(logical % (unsigned)n);
 }
 
+// scratch slots per logical GPU (all grow-only, kept across op calls)
+enum { WS_STAGING = 0, WS_PARTIAL = 1, WS_GATHER = 2, WS_SLOTS = 3 };
 struct PerGpu {
     hipStream_t stream = nullptr;
-    void *workspace = nullptr;
-    size_t workspace_bytes = 0;
+    void *workspace[WS_SLOTS] = {nullptr, nullptr, nullptr};
+    size_t workspace_bytes[WS_SLOTS] = {0, 0, 0};
 };
 inline std::map<unsigned, PerGpu> &table()
 {
@@ -99,19 +101,21 @@ inline hipStream_t stream(unsigned logical)
     return g.stream;
 }
 
-// grow-only scratch buffer per logical GPU: the "externalBuffer" of the replaced cuSPARSE calls
-// (spmm.h:134-141), kept instead of being malloc'ed and freed inside every op call
-inline void *workspace(unsigned logical, size_t bytes)
+// grow-only scratch buffers per logical GPU: the "externalBuffer" of the replaced cuSPARSE calls (spmm.h:134-141)
+// and the partial-result / gather buffers of method 2 (the reference builds a DenseMatrix C_copy and uploads M*N
+// zeros inside every call, spmm.h:182-183), kept instead of being malloc'ed and freed inside every op call
+inline void *workspace(unsigned logical, size_t bytes, int slot = WS_STAGING)
 {
     std::lock_guard<std::mutex> lock(table_mutex());
     PerGpu &g = table()[logical];
-    if (g.workspace_bytes < bytes) {
+    if (bytes == 0) bytes = 16;
+    if (g.workspace_bytes[slot] < bytes) {
         must(hipSetDevice(physical_device(logical)), "hipSetDevice");
-        if (g.workspace) must(hipFree(g.workspace), "hipFree");
-        must(hipMalloc(&g.workspace, bytes), "hipMalloc(workspace)");
-        g.workspace_bytes = bytes;
+        if (g.workspace[slot]) must(hipFree(g.workspace[slot]), "hipFree"); // (hipFree drains the device first)
+        must(hipMalloc(&g.workspace[slot], bytes), "hipMalloc(workspace)");
+        g.workspace_bytes[slot] = bytes;
     }
-    return g.workspace;
+    return g.workspace[slot];
 }
 
 inline void sync_all(unsigned n_gpu)

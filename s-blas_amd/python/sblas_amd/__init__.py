@@ -19,7 +19,7 @@ EXPORTS = [
     "sblas_hip_version", "sblas_hip_error_string", "sblas_hip_device_count",
     "sblas_hip_spmm_csr_f64_i32_workspace", "sblas_hip_spmm_csr_f64_i32", "sblas_hip_spmm_ldbt",
     "sblas_hip_dense_to_rowmajor_f64", "sblas_hip_spmm_csr_rowmajorB_f64_i32",
-    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_spmm_cycle_stamps",
+    "sblas_hip_debug_spmm_panel_stats", "sblas_hip_debug_reload_env",
     "sblas_hip_debug_spmm_kernel_events", "sblas_hip_debug_spmm_last_kernel_ms", "sblas_hip_spmv_csr_f64_i32", "sblas_hip_axpby_f64",
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
     "sblas_hip_merge_rowblocks_f64", "sblas_hip_merge_rowblocks_local_f64",
@@ -62,8 +62,8 @@ def lib():
     L.sblas_hip_dense_to_rowmajor_f64.argtypes = [C.c_int, vp, i64, i64, vp, i64, vp, i64]
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.restype = C.c_int
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64]
-    L.sblas_hip_debug_spmm_cycle_stamps.restype = C.c_int
-    L.sblas_hip_debug_spmm_cycle_stamps.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.sblas_hip_debug_reload_env.restype = C.c_int
+    L.sblas_hip_debug_reload_env.argtypes = []
     L.sblas_hip_debug_spmm_panel_stats.restype = C.c_int
     L.sblas_hip_debug_spmm_panel_stats.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.sblas_hip_debug_spmm_kernel_events.restype = C.c_int
@@ -175,9 +175,10 @@ def spmm(rows, cols, rowptr, colidx, val, B, ldb, n, alpha, beta, Cmat, ldc, wor
         -1, _stream(stream), rows, cols, nnz,
         _dev_ptr(rowptr, torch.int32, "rowptr"), _dev_ptr(colidx, torch.int32, "colidx") if nnz else None,
         _dev_ptr(val, torch.float64, "val") if nnz else None,
-        _dev_ptr(B, torch.float64, "B"), ldb, n, alpha, beta,
+        _dev_ptr(B, torch.float64, "B") if cols else None, ldb, n, alpha, beta,
         _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc,
-        _dev_ptr(workspace, torch.float64, "workspace"), workspace.numel() * 8)
+        _dev_ptr(workspace, torch.float64, "workspace") if workspace is not None and workspace.numel() else None,
+        workspace.numel() * 8 if workspace is not None else 0)
     check(rc, "sblas_hip_spmm_csr_f64_i32")
 
 
@@ -197,7 +198,7 @@ def spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, alpha, beta, Cmat, ld
         -1, _stream(stream), rows, cols, nnz,
         _dev_ptr(rowptr, torch.int32, "rowptr"), _dev_ptr(colidx, torch.int32, "colidx") if nnz else None,
         _dev_ptr(val, torch.float64, "val") if nnz else None,
-        _dev_ptr(Bt, torch.float64, "Bt"), ldbt, n, alpha, beta,
+        _dev_ptr(Bt, torch.float64, "Bt") if Bt is not None else None, ldbt, n, alpha, beta,
         _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc)
     check(rc, "sblas_hip_spmm_csr_rowmajorB_f64_i32")
 
@@ -220,10 +221,9 @@ def last_kernel_ms():
     return float(ms.value)
 
 
-def cycle_stamps(reset=True):
-    out = (C.c_uint64 * 16)()
-    check(lib().sblas_hip_debug_spmm_cycle_stamps(out, 1 if reset else 0), "sblas_hip_debug_spmm_cycle_stamps")
-    return [int(x) for x in out]
+def reload_env():
+    """Have the library re-read its SBLAS_* experiment switches (it reads the environment only once)."""
+    check(lib().sblas_hip_debug_reload_env(), "sblas_hip_debug_reload_env")
 
 
 def spmv(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offset=0):
@@ -258,3 +258,48 @@ def axpby(n, alpha, x, beta, y, stream=None):
     import torch
     px, py = _dev_ptr(x, torch.float64, "x"), _dev_ptr(y, torch.float64, "y")
     check(lib().sblas_hip_axpby_f64(-1, _stream(stream), n, alpha, px, beta, py), "sblas_hip_axpby_f64")
+
+
+# ------------------------------------------------------------------------------------------
+# one process driving several GPUs (the reference's process model): comm.hip through the C ABI
+# ------------------------------------------------------------------------------------------
+def comm_get(devs):
+    """Persistent communicator set over the device list `devs` (sblas_hip_comm_get).  All equal = ranks folded onto one
+    device (on-device sum / no copies); all distinct = RCCL over xGMI."""
+    arr = (C.c_int * len(devs))(*[int(d) for d in devs])
+    out = C.c_void_p()
+    check(lib().sblas_hip_comm_get(len(devs), arr, C.byref(out)), "sblas_hip_comm_get")
+    return out
+
+
+def _ptr_array(tensors, what, allow_none=False):
+    import torch
+    vals = []
+    for t in tensors:
+        if t is None or (allow_none and t.numel() == 0):
+            vals.append(None)
+        else:
+            vals.append(_dev_ptr(t, torch.float64, what))
+    return (C.c_void_p * len(vals))(*vals)
+
+
+def _stream_array(streams):
+    return (C.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+
+
+def allreduce_sum(comm, bufs, streams, count):
+    """In-place sum of bufs[r] (rank r's buffer on rank r's device / stream): sblas_hip_allreduce_sum_f64."""
+    check(lib().sblas_hip_allreduce_sum_f64(comm, _ptr_array(bufs, "buf"), _stream_array(streams), count),
+          "sblas_hip_allreduce_sum_f64")
+
+
+def merge_rowblocks(comm, M, N, starts, nrows, partial, gather, alpha, beta, Cs, ldc, streams):
+    """Method-2 / SpMV merge over the ranks of `comm`: exchange the packed row blocks (RCCL send/recv; folded ranks
+    skip the copies) and scatter + alpha/beta on every rank (sblas_hip_merge_rowblocks_f64)."""
+    g = len(partial)
+    st = (C.c_int64 * g)(*[int(v) for v in starts])
+    nr = (C.c_int64 * g)(*[int(v) for v in nrows])
+    ga = _ptr_array(gather, "gather", allow_none=True) if gather is not None else None
+    check(lib().sblas_hip_merge_rowblocks_f64(comm, M, N, st, nr, _ptr_array(partial, "partial", allow_none=True), ga,
+                                              alpha, beta, _ptr_array(Cs, "C"), ldc, _stream_array(streams)),
+          "sblas_hip_merge_rowblocks_f64")

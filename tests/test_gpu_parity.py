@@ -11,6 +11,9 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
+# SBLAS_SPMM_VARIANT values (kernels.h): every stage-2 selection the library can be pinned to
+SPMM_VARIANTS = ["auto", "dpp", "rows", "lanes", "grid2d", "mfma", "nomfma"]
+
 RTOL = 1e-10          # north_star: "fp64 within 1e-10 rel"
 ATOL = 1e-12          # floor for results near zero (inputs are O(1), sums O(1e2))
 
@@ -34,7 +37,8 @@ class Dev:
 def gpu_spmm(sblas, torch, dev, A, B_host, ldb, n, alpha, beta, C_host, ldc):
     B = torch.from_numpy(B_host).to(dev)
     C = torch.from_numpy(C_host.copy()).to(dev)
-    ws = torch.empty(max(1, sblas.spmm_workspace_bytes(A.rows, A.cols, len(A.h[1]), n) // 8), dtype=torch.float64, device=dev)
+    nbytes = sblas.spmm_workspace_bytes(A.rows, A.cols, len(A.h[1]), n)
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=dev) if nbytes else None   # 0 bytes: a NULL workspace
     sblas.spmm(A.rows, A.cols, A.rowptr, A.colidx, A.val, B, ldb, n, alpha, beta, C, ldc, ws)
     torch.cuda.synchronize()
     return C.cpu().numpy()
@@ -52,14 +56,30 @@ def oracle_spmm_ld(oracle, A, B_host, ldb, n, alpha, beta, C_host, ldc):
     return Cfull
 
 
+def _env_switch(name):
+    """Set an SBLAS_* switch for one test; the library caches its switches, so tell it to read them again."""
+    import sblas_amd
+    old = os.environ.get(name)
+
+    def setter(v):
+        os.environ[name] = v
+        sblas_amd.reload_env()
+    yield setter
+    if old is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = old
+    sblas_amd.reload_env()
+
+
 @pytest.fixture
 def variant_env():
-    old = os.environ.get("SBLAS_SPMM_VARIANT")
-    yield lambda v: os.environ.__setitem__("SBLAS_SPMM_VARIANT", v)
-    if old is None:
-        os.environ.pop("SBLAS_SPMM_VARIANT", None)
-    else:
-        os.environ["SBLAS_SPMM_VARIANT"] = old
+    yield from _env_switch("SBLAS_SPMM_VARIANT")
+
+
+@pytest.fixture
+def panel_rows_env():
+    yield from _env_switch("SBLAS_SPMM_PANEL_ROWS")
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +125,7 @@ def test_ash85_spmm_known_answers(env, ash85, key):
     assert oracle.lib().orc_check_equal(ref, got, got.size) == 1          # the reference's own criterion (1e-3 abs)
 
 
-@pytest.mark.parametrize("variant", ["auto", "dpp", "rows", "direct", "win2", "win3", "win4", "win5", "win6"])
+@pytest.mark.parametrize("variant", SPMM_VARIANTS)
 @pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128, 130, 256])
 def test_spmm_every_column_count(env, variant_env, variant, n):
     sblas, oracle, torch, dev = env
@@ -138,12 +158,14 @@ def test_spmm_narrow_kernels_still_correct(env, ash85, n):
     try:
         for setting in ("0", "64"):
             os.environ["SBLAS_SPMM_MIN_LDBT"] = setting
+            sblas.reload_env()
             assert close(gpu_spmm(sblas, torch, dev, A, B, rows, n, 0.5, 2.0, C0, rows), ref), (n, setting)
     finally:
         if old is None:
             os.environ.pop("SBLAS_SPMM_MIN_LDBT", None)
         else:
             os.environ["SBLAS_SPMM_MIN_LDBT"] = old
+        sblas.reload_env()
 
 
 @pytest.mark.parametrize("n", [8, 64, 96])
@@ -183,7 +205,7 @@ def test_spmm_nonfinite_b_rows_not_referenced_stay_out(env, variant_env):
     B[:, 0] = np.nan
     B = np.ascontiguousarray(B).reshape(-1)
     C0 = rng.standard_normal(rows * n)
-    for variant in ("dpp", "rows", "win64", "win2", "win3", "win4", "win5", "win6", "auto"):
+    for variant in SPMM_VARIANTS:
         variant_env(variant)
         got = gpu_spmm(sblas, torch, dev, A, B, rows, n, 1.0, 1.0, C0, rows)
         ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), 1.0, 1.0)
@@ -212,6 +234,27 @@ def test_spmm_degenerate_shapes(env, variant_env, variant):
     C0 = np.arange(10 * 64, dtype=np.float64)
     got = gpu_spmm(sblas, torch, dev, A, np.ones(6 * 64), 6, 64, 1.0, 3.0, C0, 10)
     assert (got == 3.0 * C0).all()
+    # K = 0 (no columns at all), rows > 0, wide N: C = beta*C with no workspace (this shape used to reach
+    # the kernels with a NULL staging copy); beta = 0 must clear C without reading it
+    A0 = Dev(torch, dev, np.zeros(301, np.int32), np.zeros(0, np.int32), np.zeros(0), 0)
+    for n0 in (1, 8, 64, 130):
+        Cn = np.arange(300 * n0, dtype=np.float64) + 1.0
+        assert sblas.spmm_workspace_bytes(300, 0, 0, n0) == 0
+        got = gpu_spmm(sblas, torch, dev, A0, np.zeros(1), 1, n0, 2.0, -1.5, Cn, 300)
+        assert (got == -1.5 * Cn).all(), n0
+        got = gpu_spmm(sblas, torch, dev, A0, np.zeros(1), 1, n0, 2.0, 0.0, np.full(300 * n0, np.nan), 300)
+        assert (got == 0.0).all(), n0
+    # ... and through the split entry point (no staging copy exists for K = 0)
+    Cd = torch.from_numpy(np.arange(300 * 64, dtype=np.float64)).to(dev)
+    sblas.spmm_rowmajorB(300, 0, A0.rowptr, A0.colidx, A0.val, None, 64, 1.0, 0.5, Cd, 300)
+    assert (Cd.cpu().numpy() == 0.5 * np.arange(300 * 64)).all()
+    # nnz = 0 with K > 0 and a padded C (ldc > rows): the padding rows stay untouched
+    Cp = np.arange(12 * 64, dtype=np.float64)
+    A = Dev(torch, dev, rp, np.zeros(0, np.int32), np.zeros(0), 6)
+    got = gpu_spmm(sblas, torch, dev, A, np.ones(6 * 64), 6, 64, 1.0, 3.0, Cp, 12).reshape(64, 12)
+    want = Cp.copy().reshape(64, 12)
+    want[:, :10] *= 3.0
+    assert (got == want).all()
     # one row, one column, one nonzero
     A = Dev(torch, dev, np.array([0, 1], np.int32), np.array([0], np.int32), np.array([2.0]), 1)
     got = gpu_spmm(sblas, torch, dev, A, np.array([4.0]), 1, 1, 1.0, 1.0, np.array([1.0]), 1)
@@ -349,6 +392,146 @@ def test_method2_rowblock_merge_fast_path(env, ash85, g, case):
     assert close(y.cpu().numpy(), oracle.spmv(M, rp, ci, v, xh, np.zeros(M), 2.0, 0.0))
 
 
+def _config4_blocks(sblas, torch, dev_of, rp, ci, v, K, g):
+    """The nnz row-block partition of CsrSparseMatrix::sync2gpu(segment) (matrix.h:356-395), block q on dev_of(q)."""
+    blocks = []
+    for q in range(g):
+        d = sblas.partition_nnz(rp, g, q)
+        lo, k = d["first_nnz"], d["nnz"]
+        blocks.append(dict(start=d["start_row"], m=len(d["rowptr"]) - 1, nnz=k,
+                           A=Dev(torch, dev_of(q), d["rowptr"], ci[lo:lo + k], v[lo:lo + k], K)))
+    return blocks
+
+
+def _config4_run(sblas, oracle, torch, devs, rows, rp, ci, v, N, merge, check_rows=None):
+    """BASELINE config 4: method 2, g = len(devs) nnz row blocks, N dense columns, both merges of spmm.h's v2.
+    devs all equal: ranks folded onto one device (how the 1-GPU box rehearses it); distinct: RCCL over xGMI."""
+    g, K, M = len(devs), rows, rows
+    alpha, beta = 3.0, 4.0
+    tdev = [torch.device("cuda", d) for d in devs]
+    Bh = oracle.rand0to1(K * N)                                   # the reference's B (matrix.h:519-528)
+    C0 = np.ones(M * N)
+    blocks = _config4_blocks(sblas, torch, lambda q: tdev[q], rp, ci, v, K, g)
+    comm = sblas.comm_get(devs)
+    Bs, Cs, streams, part, gath, ws = [], [], [], [], [], []
+    total_blocks = sum(b["m"] for b in blocks) * N
+    for q in range(g):
+        with torch.cuda.device(tdev[q]):
+            Bs.append(torch.from_numpy(Bh).to(tdev[q]))
+            Cs.append(torch.from_numpy(C0.copy()).to(tdev[q]))
+            streams.append(torch.cuda.Stream(device=tdev[q]))
+            b = blocks[q]
+            ws.append(torch.empty(max(sblas.spmm_workspace_bytes(b["m"], K, b["nnz"], N) // 8, 1), dtype=torch.float64, device=tdev[q]))
+            if merge == "allreduce":                              # spmm.h:182-183, 248-251: zeroed M x N, ldc = M
+                part.append(torch.zeros(M * N, dtype=torch.float64, device=tdev[q]))
+            else:                                                 # packed m_q x N, beta = 0
+                part.append(torch.full((max(b["m"] * N, 1),), 7.0, dtype=torch.float64, device=tdev[q]))
+                gath.append(torch.empty(max(total_blocks, 1), dtype=torch.float64, device=tdev[q]))
+    torch.cuda.synchronize()
+    for q in range(g):
+        b = blocks[q]
+        with torch.cuda.device(tdev[q]):
+            if b["m"] == 0:
+                continue
+            if merge == "allreduce":
+                sblas.spmm(b["m"], K, b["A"].rowptr, b["A"].colidx, b["A"].val, Bs[q], K, N, 1.0, 1.0, part[q], M, ws[q],
+                           stream=streams[q], c_offset=b["start"])
+            else:
+                sblas.spmm(b["m"], K, b["A"].rowptr, b["A"].colidx, b["A"].val, Bs[q], K, N, 1.0, 0.0, part[q], b["m"], ws[q],
+                           stream=streams[q])
+    if merge == "allreduce":
+        sblas.allreduce_sum(comm, part, streams, M * N)           # spmm.h:260-262
+        for q in range(g):
+            with torch.cuda.device(tdev[q]):
+                sblas.axpby(M * N, alpha, part[q], beta, Cs[q], stream=streams[q])   # spmm.h:283
+    else:
+        sblas.merge_rowblocks(comm, M, N, [b["start"] for b in blocks], [b["m"] for b in blocks], part, gath, alpha, beta,
+                              Cs, M, streams)
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    if check_rows is None:
+        ref = oracle.spmm(M, K, N, rp, ci, v, Bh, C0.copy(), alpha, beta)
+        for q in range(g):
+            got = Cs[q].cpu().numpy()
+            assert close(got, ref), (merge, q, np.abs(got - ref).max())
+    else:                                                         # full size: row windows against the oracle
+        ref = C0.copy()
+        for r0 in check_rows:
+            oracle.spmm_rows(r0, r0 + 64, M, K, N, rp, ci, v, Bh, ref, alpha, beta)
+        for q in range(g):
+            got = Cs[q].view(N, M).cpu().numpy()
+            for r0 in check_rows:
+                assert close(got[:, r0:r0 + 64], ref.reshape(N, M)[:, r0:r0 + 64]), (merge, q, r0)
+        # every rank holds the same C (bit for bit with the row-block merge: same terms in the same order)
+        for q in range(1, g):
+            if merge != "allreduce":
+                assert torch.equal(Cs[q].cpu(), Cs[0].cpu())
+    return Cs[0]
+
+
+@pytest.mark.parametrize("merge", ["allreduce", "rowblocks"])
+def test_config4_method2_n128_g4(env, merge):
+    """BASELINE config 4 at reduced rows (nd24k-like, 399 per row; the oracle finishes in seconds): method 2, g = 4 nnz
+    row blocks, N = 128, the reference's call pattern (spmm.h:199-251: ldc = M != m_i, C view at start_row) with the
+    all-reduce merge, and the packed beta = 0 form with the row-block merge -- every rank's full C against the oracle."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, (rp, ci, v) = synth.nd24k_like(scale=0.05)
+    _config4_run(sblas, oracle, torch, [dev.index or 0] * 4, rows, rp, ci, v, 128, merge)
+
+
+@pytest.mark.parametrize("merge", ["allreduce", "rowblocks"])
+def test_config4_method2_full_size(env, merge):
+    """The same at BASELINE's full 72 000 rows: row windows at both ends, at a block boundary and in the middle against
+    the oracle, and the ranks' results identical."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, (rp, ci, v) = synth.nd24k_like()
+    cut = sblas.partition_nnz(rp, 4, 1)["start_row"]
+    _config4_run(sblas, oracle, torch, [dev.index or 0] * 4, rows, rp, ci, v, 128, merge,
+                 check_rows=[0, max(cut - 32, 0), rows // 2, rows - 64])
+
+
+@pytest.mark.parametrize("merge", ["allreduce", "rowblocks"])
+@pytest.mark.parametrize("g", [2, 4])
+def test_method2_over_real_devices(env, merge, g):
+    """comm.hip's multi-device branches (ncclCommInitAll, grouped ncclAllReduce, grouped ncclSend / ncclRecv) over
+    DISTINCT devices -- runs wherever the process sees at least g GPUs (the round-end 8-GPU node); on the one-GPU box
+    the same code runs folded (the tests above)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    if torch.cuda.device_count() < g:
+        pytest.skip("needs %d GPUs, this box has %d (the folded variant above ran instead)" % (g, torch.cuda.device_count()))
+    rows, (rp, ci, v) = synth.nd24k_like(scale=0.05)
+    _config4_run(sblas, oracle, torch, list(range(g)), rows, rp, ci, v, 128, merge)
+    # SpMV merge (N = 1) over the same communicator
+    comm = sblas.comm_get(list(range(g)))
+    xh = np.random.default_rng(2).standard_normal(rows)
+    yh = np.random.default_rng(3).standard_normal(rows)
+    parts, ys, streams, starts, nrows = [], [], [], [], []
+    for q in range(g):
+        d = sblas.partition_nnz(rp, g, q)
+        lo, k = d["first_nnz"], d["nnz"]
+        td = torch.device("cuda", q)
+        with torch.cuda.device(td):
+            Ai = Dev(torch, td, d["rowptr"], ci[lo:lo + k], v[lo:lo + k], rows)
+            m_i = len(d["rowptr"]) - 1
+            st = torch.cuda.Stream(device=td)
+            yb = torch.zeros(max(m_i, 1), dtype=torch.float64, device=td)
+            x = torch.from_numpy(xh).to(td)
+            torch.cuda.synchronize(td)
+            sblas.spmv(m_i, rows, Ai.rowptr, Ai.colidx, Ai.val, x, 1.0, 0.0, yb, stream=st)
+            parts.append(yb); streams.append(st); starts.append(d["start_row"]); nrows.append(m_i)
+            ys.append(torch.from_numpy(yh.copy()).to(td))
+    gath = [torch.empty(max(sum(nrows), 1), dtype=torch.float64, device=torch.device("cuda", q)) for q in range(g)]
+    sblas.merge_rowblocks(comm, rows, 1, starts, nrows, parts, gath, 2.0, -1.0, ys, rows, streams)
+    for q in range(g):
+        torch.cuda.synchronize(q)
+    ref = oracle.spmv(rows, rp, ci, v, xh, yh.copy(), 2.0, -1.0)
+    for q in range(g):
+        assert close(ys[q].cpu().numpy(), ref), q
+
+
 @pytest.mark.parametrize("avg", [1, 3, 7, 15, 30, 70, 400])
 def test_spmv_every_row_length_class(env, avg):
     """One case per lanes-per-row instantiation (4..64), unsorted rows, empty rows, a long row."""
@@ -446,7 +629,7 @@ def test_full_size_properties(env):
 # ---------------------------------------------------------------------------------------------------------
 # the windowed (row panel x LDS B tile) kernel and its per-panel fallback
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["direct", "dpp", "rows", "win2", "win3", "win4", "win5", "win6", "win32", "win64", "win128", "win64w64", "win32w128", "auto"])
+@pytest.mark.parametrize("variant", SPMM_VARIANTS)
 @pytest.mark.parametrize("shape", [(1000, 40, 100, 64), (777, 60, 300, 130), (200, 30, 20, 64), (90, 80, 45, 256)])
 def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     """Banded, ascending rows: dense enough over their span that the windowed path is taken.  Covers several
@@ -464,7 +647,7 @@ def test_spmm_windowed_variants_banded(env, variant_env, variant, shape):
     assert close(got, ref), (variant, shape, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["win2", "win3", "win4", "win5", "win6", "win32", "win64", "win128", "win64w64"])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma"])
 @pytest.mark.parametrize("damage", ["all_descending", "one_row_shuffled", "first_col_not_min", "duplicates"])
 def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, damage):
     """The windowed path expects ascending columns but must never depend on it: panels whose rows break the
@@ -501,7 +684,7 @@ def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, dama
     assert close(got, ref), (variant, damage, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["win32", "win64", "win128", "win64w64"])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma", "grid2d"])
 def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     """Dense-band panels next to sparse wide-span panels (direct path chosen per panel), empty rows, rows longer
     than several chunks, and a method-2 style row block (re-based row pointers, C offset, ldc > rows)."""
@@ -544,12 +727,13 @@ def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     assert close(Cd.cpu().numpy(), want.reshape(-1))
 
 
-def test_spmm_panel_census_paths_are_really_taken(env, variant_env):
-    """The parity tests above cannot tell a windowed run from a fallback run; the census can.  (win2: 48-row
-    panels; [0] windowed, [1] direct kernel, [2] windowed but recomputed by the in-kernel fallback.)"""
+def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_env):
+    """The parity tests above cannot tell a windowed run from a fallback run; the census can.  (SBLAS_SPMM_PANEL_ROWS
+    pins 48-row panels; [0] windowed, [1] direct kernel, [2] windowed but recomputed by the in-kernel fallback.)"""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
-    variant_env("win2")
+    variant_env("nomfma")
+    panel_rows_env("48,2")
     n = 64
 
     def run(rp, ci, v, rows, cols):
@@ -571,22 +755,16 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env):
     assert run(rp, ci2, v2, rows, rows) == (9, 0, 1)                      # that panel recomputed, others not
     rp3, ci3, v3 = synth.random_csr(rows, 5000, 6, seed=3, sorted_rows=True)
     assert run(rp3, ci3, v3, rows, 5000) == (0, 10, 0)                    # too sparse over its span: direct kernel
-    rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows longer than the register budget (7*64)
-    w, d, f = run(rp4, ci4, v4, rows, rows)                               # (edge panels have shorter rows)
-    assert d >= 8 and f == 0 and w + d == 10
+    rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows of 500: several windows per (row, tile) visit
+    assert run(rp4, ci4, v4, rows, rows) == (10, 0, 0)
 
 
 @pytest.fixture
 def spmv_variant_env():
-    old = os.environ.get("SBLAS_SPMV_VARIANT")
-    yield lambda v: os.environ.__setitem__("SBLAS_SPMV_VARIANT", v)
-    if old is None:
-        os.environ.pop("SBLAS_SPMV_VARIANT", None)
-    else:
-        os.environ["SBLAS_SPMV_VARIANT"] = old
+    yield from _env_switch("SBLAS_SPMV_VARIANT")
 
 
-@pytest.mark.parametrize("variant", ["plain", "burst", "window", "flat2", "flat4", "flat8", "lds", "lds2", "lds2s4", "lds1s2", "lds1s3", "auto", "seg2", "seg3", "seg4", "seg8"])
+@pytest.mark.parametrize("variant", ["plain", "lds", "lds2", "lds1s2", "lds1s3", "lds1s4", "auto", "seg2", "seg3", "seg4", "seg8", "stream"])
 @pytest.mark.parametrize("kind", ["banded", "unsorted", "wide_span", "outliers"])
 def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
     """Long rows (the 64-lanes-per-row instantiation, unrolled four slices deep): banded, shuffled, very wide spans
@@ -617,6 +795,39 @@ def test_spmv_long_rows_any_structure(env, spmv_variant_env, variant, kind):
         sblas.spmv(M, K, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
         ref = oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)
         assert close(y.cpu().numpy(), ref), (kind, alpha, beta)
+
+
+@pytest.mark.parametrize("variant", ["auto", "lds", "lds1s2", "lds1s3", "lds2"])
+def test_spmv_unstaged_window_never_multiplies_stale_lds(env, spmv_variant_env, variant):
+    """a 16-row block whose rows span more columns than the LDS window stages nothing; its clamped lanes
+    must not multiply by whatever an earlier kernel left in LDS.  The staging kernel run first leaves NaN tiles at
+    the start of every CU's LDS; row lengths are not multiples of 64 so that every row has clamped lanes, and x
+    holds an Inf at a column only the LAST entry of a row refers to (0 * Inf in a clamped lane would be a NaN)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    spmv_variant_env(variant)
+    M = K = 30000
+    rp, ci, v = synth.banded(M, 101, 9000)            # span 18 000 columns > 5120: nothing staged
+    rp2, ci2, v2 = synth.banded(4000, 133, 1500)      # span 3000: staged, last column of row 7 gets an Inf in x
+    nanB = torch.full((4096 * 64,), float("nan"), dtype=torch.float64, device=dev)
+    Bt = torch.empty(sblas.spmm_workspace_bytes(1, 4096, 1, 64) // 8, dtype=torch.float64, device=dev)
+    for (m, k, rp_, ci_, v_) in ((M, K, rp, ci, v), (4000, 4000, rp2, ci2, v2)):
+        A = Dev(torch, dev, rp_, ci_, v_, k)
+        xh = np.random.default_rng(8).standard_normal(k)
+        if m == 4000:
+            last = int(ci_[rp_[8] - 1])
+            only_last = not np.isin(last, np.delete(ci_, rp_[8] - 1))
+            if only_last:
+                xh[last] = np.inf
+        yh = np.random.default_rng(9).standard_normal(m)
+        sblas.dense_to_rowmajor(4096, 64, nanB, 4096, Bt)                     # NaN tiles in every CU's LDS
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(m, k, A.rowptr, A.colidx, A.val, x, 1.5, -0.5, y)
+        got = y.cpu().numpy()
+        ref = oracle.spmv(m, *A.h, xh, yh.copy(), 1.5, -0.5)
+        fin = np.isfinite(ref)
+        assert (np.isfinite(got) == fin).all() and not np.isnan(got).any(), variant
+        assert close(got[fin], ref[fin]) and (got[~fin] == ref[~fin]).all()
 
 
 @pytest.mark.parametrize("xoff", [0, 1])
@@ -727,6 +938,7 @@ def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
     full = sblas.spmm_workspace_bytes(M, K, len(ci), n)
     for limit, width in ((8 * 701 * 128, 128), (8 * 701 * 64, 64), (8 * 701 * 40, 32)):
         os.environ["SBLAS_SPMM_MAX_BT_BYTES"] = str(limit)
+        sblas.reload_env()
         try:
             ws = sblas.spmm_workspace_bytes(M, K, len(ci), n)
             if n > width:
@@ -734,6 +946,7 @@ def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
             got = gpu_spmm(sblas, torch, dev, A, B, K, n, 1.5, -1.0, C0, M)
         finally:
             os.environ.pop("SBLAS_SPMM_MAX_BT_BYTES", None)
+            sblas.reload_env()
         assert close(got, ref), (n, width, np.abs(got - ref).max())
 
 
@@ -799,13 +1012,18 @@ def test_spmm_and_spmv_inside_a_hip_graph(env, kind):
 
 @pytest.mark.parametrize("n", [1, 3, 8])
 @pytest.mark.parametrize("kind", ["banded", "ragged"])
-def test_spmm_up_to_eight_columns_long_rows(env, monkeypatch, n, kind):
+def test_spmm_up_to_eight_columns_long_rows(env, n, kind):
     """N <= 8 with long rows takes the wave-per-row kernel (eight sums per lane, halving exchange) from 256 nonzeros
     per row on average; the test moves the switch-over down with SBLAS_ROWS8_MIN_AVG.  Row counts that are not a multiple of 4, empty rows, one row of 3000, lengths that are not a multiple of
     64 or 256; an Inf in a row of B that no nonzero refers to must not leak in through the padding lanes."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
-    monkeypatch.setenv("SBLAS_ROWS8_MIN_AVG", "96")
+    for setter in _env_switch("SBLAS_ROWS8_MIN_AVG"):
+        setter("96")
+        _eight_columns_long_rows(sblas, oracle, torch, dev, synth, n, kind)
+
+
+def _eight_columns_long_rows(sblas, oracle, torch, dev, synth, n, kind):
     if kind == "banded":
         rows = 2999
         rp, ci, v = synth.banded(rows, 150, 700)
