@@ -80,7 +80,8 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
 
 /* Diagnostics (synchronises the current device): how many row panels of the SpMM launches since the last reset
  * took the LDS-windowed path [0], the direct path because they are too sparse over their column span [1], or were
- * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2].  out[3] = 0. */
+ * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2], or the matrix-core
+ * (MFMA) path [3]. */
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
 /* The library reads its experiment switches (SBLAS_SPMM_VARIANT, SBLAS_SPMV_VARIANT, ...; none changes a result) from
  * the environment once, at the first launch.  A process that changes them afterwards (the test-suite does) calls this

@@ -122,8 +122,7 @@ size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t 
     // row panel (the panel classifier's verdicts)
     const int64_t w = spmm_chunk_cols(cols, n);
     const size_t bt = ((size_t)cols + 1) * (size_t)chunk_ldbt(cols, n, w) * sizeof(double);
-    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + sblas::SPMM_MIN_PANEL_ROWS - 1) / sblas::SPMM_MIN_PANEL_ROWS;
-    return bt + panels * 8 + 16; // + one spare entry and the widest-span slot read by the direct kernel
+    return bt + sblas::workspace_tail_bytes(rows); // flags, one span and one class per row panel
 }
 
 int sblas_hip_dense_to_rowmajor_f64(int dev, void *stream, int64_t cols, int64_t n, const double *B,
@@ -202,7 +201,7 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
             DeviceScope scope(dev);
             if (scope.err != hipSuccess) return SBLAS_E_HIP;
             if (sblas::launch_stage_classify((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, (int)rows, rowptr,
-                                             colidx, &pre_epoch) != hipSuccess)
+                                             colidx, spmm_variant(), &pre_epoch) != hipSuccess)
                 return SBLAS_E_HIP;
         } else {
             rc = sblas_hip_dense_to_rowmajor_f64(dev, stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt);

@@ -21,7 +21,24 @@ enum {
     SPMM_VARIANT_MFMA = 5,        // "mfma":  LDS-tiled panels through the MFMA kernel whatever their block density
     SPMM_VARIANT_NO_MFMA = 6,     // "nomfma": never the MFMA kernel
 };
-constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (one int2 of workspace per panel)
+constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (the workspace tail has room for rows / 32 panels)
+
+// Workspace layout behind the staging copy Bt ((cols + 1) x ldbt doubles): TAIL_HDR ints, then one int2 (column span) per
+// panel, then one int (class) per panel.
+enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pass met an Inf / NaN in B
+       TAIL_STAGE_EPOCH = 1,  // epoch of the staging pass that wrote Bt
+       TAIL_DIRECT_EPOCH = 2, // epoch of the classifier run that left panels to the direct kernel
+       TAIL_BAND = 3,         // column span of the middle panel (band width of the matrix)
+       TAIL_MFMA_EPOCH = 4,   // epoch of the classifier run that gave panels to the matrix-core kernel
+       TAIL_HDR = 16 };
+enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3 };
+constexpr int MFMA_MAX_WAVES = 9; // 16 rows per wave: panels of up to 144 rows
+size_t workspace_tail_bytes(int64_t rows);
+unsigned long long *panel_stats_device();
+hipError_t launch_spmm_mfma(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx, const double *val,
+                            const double *Bt, int64_t ldbt, int n, double alpha, double beta, double *C, int64_t ldc,
+                            const int2 *info, const int *tail, const int *cls, int panel_rows, int npanels, int epoch,
+                            unsigned long long *stats);
 
 // Experiment / test switches, read from the environment once (kernels.hip); options_reload() re-reads them.
 struct Options {
@@ -34,6 +51,7 @@ struct Options {
     double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
     int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE
+    float mfma_min_fill = 0.40f;          // SBLAS_MFMA_MIN_FILL: block fill from which a panel takes the MFMA kernel
 };
 const Options &options();
 void options_reload();
@@ -45,7 +63,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
                                 double beta, double *C, int64_t ldc, int variant, int pre_epoch = 0);
 hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
-                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int *epoch_out);
+                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int variant,
+                                 int *epoch_out);
 hipError_t launch_scale(hipStream_t s, int64_t rows, int64_t n, double beta, double *C, int64_t ldc);
 hipError_t panel_stats(unsigned long long out[4], bool reset);
 hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,

@@ -52,9 +52,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)
 // of the bench shape are resident at once (64 x 64 tiles, 33 KB: four per CU, 1126 tiles = one round and a tenth).
 // ---------------------------------------------------------------------------------------------
 constexpr int STAGE_K = 32;
+// While it is at it the pass looks for non-finite values in B: tail[TAIL_NONFINITE] = stage_epoch when it meets one
+// (every writer stores the same value), and tail[TAIL_STAGE_EPOCH] = stage_epoch always -- the two agree exactly when
+// the staging copy the stage-2 kernels are about to read holds an Inf or NaN (the MFMA kernel then leaves its panels
+// to the vector kernels: 0 * Inf from a block's zero fill would reach rows that never refer to that row of B).
 __device__ __forceinline__ void stage_tile(double (*tile)[STAGE_K + 1], int64_t k0, int64_t j0, int64_t cols, int64_t n,
                                            const double *__restrict__ B, int64_t ldb, double *__restrict__ Bt,
-                                           int64_t ldbt)
+                                           int64_t ldbt, int *__restrict__ tail, int stage_epoch)
 {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     // all eight loads of a thread in flight before the first LDS store (the kernel is latency-bound otherwise)
@@ -65,6 +69,11 @@ __device__ __forceinline__ void stage_tile(double (*tile)[STAGE_K + 1], int64_t 
         const int64_t j = j0 + ty + 8 * u;
         v[u] = (j < n && k < cols) ? B[k + j * ldb] : 0.0;
     }
+    bool odd = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) odd |= (__double2hiint(v[u]) & 0x7ff00000) == 0x7ff00000;
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull && (threadIdx.x & 63) == 0) tail[TAIL_NONFINITE] = stage_epoch;
+    if (k0 == 0 && j0 == 0 && threadIdx.x == 0) tail[TAIL_STAGE_EPOCH] = stage_epoch;
 #pragma unroll
     for (int u = 0; u < 8; ++u) tile[ty + 8 * u][tx] = v[u];
     __syncthreads();
@@ -80,10 +89,12 @@ __device__ __forceinline__ void stage_tile(double (*tile)[STAGE_K + 1], int64_t 
 }
 __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, int64_t n,
                                                                const double *__restrict__ B, int64_t ldb,
-                                                               double *__restrict__ Bt, int64_t ldbt)
+                                                               double *__restrict__ Bt, int64_t ldbt,
+                                                               int *__restrict__ tail, int stage_epoch)
 {
     __shared__ double tile[64][STAGE_K + 1];
-    stage_tile(tile, (int64_t)blockIdx.x * STAGE_K, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt);
+    stage_tile(tile, (int64_t)blockIdx.x * STAGE_K, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt, ldbt, tail,
+               stage_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -162,17 +173,25 @@ constexpr int W2_ROWS = 128;              // Bt rows per LDS tile
 constexpr int W2_TILE = W2_ROWS * 64;     // doubles
 constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64 * sizeof(int);
 
-// info[p] = (cmin, cmax) of panel p when it should take the windowed path, (1, 0) otherwise.
-// One wave per panel, one lane per row.
+// The panel classifier.  One wave per panel, one lane per row.  Verdicts (workspace tail, kernels.h):
+//   info[p] = column span (first, last) of panel p, (1, 0) for an empty panel;
+//   cls[p]  = PANEL_WINDOW  dense enough over its span for the LDS-tiled kernel,
+//             PANEL_MFMA_W / PANEL_MFMA_D  its nonzeros sit in dense 16 x 4 sub-blocks (sampled: fill of the blocks
+//             its first 16 rows touch >= mfma_min_fill): the matrix-core kernel, and the windowed (W) or direct (D)
+//             kernel should stage 1 have met a non-finite B,
+//             PANEL_DIRECT  everything else.
+// bitmap: MFMA_BITMAP_WORDS ints of LDS per wave (one bit per 4-column block of the sampled rows' span).
+constexpr int MFMA_BITMAP_WORDS = 1024; // 32768 blocks = 131072 columns of span
 __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int npanels, int panel_rows,
                                                const int *__restrict__ rowptr, const int *__restrict__ colidx,
-                                               int max_row_len, float min_density, int2 *__restrict__ info,
-                                               int epoch)
+                                               int max_row_len, float min_density, float mfma_min_fill,
+                                               int *__restrict__ tail, int2 *__restrict__ info, int *__restrict__ cls,
+                                               int epoch, unsigned *__restrict__ bitmap)
 {
     const int lane = threadIdx.x & 63;
     if (p >= npanels) return;
     int first = 0x7fffffff, last = -1, len = 0, mlen = 0;
-    for (int rr = lane; rr < panel_rows; rr += WAVE) { // panels of up to 128 rows: two rows per lane
+    for (int rr = lane; rr < panel_rows; rr += WAVE) { // panels of up to 144 rows: up to three rows per lane
         const int row = p * panel_rows + rr;
         if (row < rows) {
             const int a = rowptr[row], b = rowptr[row + 1];
@@ -192,56 +211,96 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         nnz += __shfl_xor(nnz, m, WAVE);
         mlen = max(mlen, __shfl_xor(mlen, m, WAVE));
     }
+    const bool sane = last >= first && first >= 0 && last < cols; // (first / last of sorted rows; the kernels re-check)
+    const bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1);
+    // block fill of the first 16 rows: their entries are one contiguous run of the CSR arrays
+    bool mfma = false;
+    if (sane && mfma_min_fill <= 1.0f) {
+        const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
+        const int e0 = rowptr[r0], e1 = rowptr[r1];
+        const int blo = first >> 2;
+        if (e1 > e0 && ((last >> 2) - blo) < MFMA_BITMAP_WORDS * 32) {
+            for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) bitmap[w] = 0u;
+            bool in_range = true;
+            for (int e = e0 + lane; e < e1; e += WAVE) {
+                const unsigned blk = (unsigned)((colidx[e] >> 2) - blo);
+                if (blk < (unsigned)(MFMA_BITMAP_WORDS * 32)) atomicOr(&bitmap[blk >> 5], 1u << (blk & 31));
+                else in_range = false; // an unsorted row's entry outside [first, last]: not a candidate
+            }
+            int nblk = 0;
+            for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) nblk += __popc(bitmap[w]);
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) nblk += __shfl_xor(nblk, m, WAVE);
+            mfma = __builtin_amdgcn_ballot_w64(!in_range) == 0ull &&
+                   (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
+        }
+    }
     if (lane == 0) {
-        const bool ok = last >= first && first >= 0 && last < cols && mlen <= max_row_len &&
-                        (float)nnz >= min_density * (float)(last - first + 1);
-        // windowed: (first, last).  Direct: x > y, and for a non-empty panel the span stays recoverable
-        // (first = -1 - x, last = -2 - y): the direct kernel samples three panels to choose its panel -> XCD map
-        info[p] = ok ? make_int2(first, last) : (last >= first ? make_int2(-1 - first, -2 - last) : make_int2(1, 0));
-        // the middle panel's column span, copied to the slot after the verdicts (one writer): the direct kernel takes
-        // it as the band width of the matrix when it chooses its panel -> XCD map
-        if (p == npanels / 2) info[npanels] = make_int2(last >= first ? last - first + 1 : 0, 0);
-        // "this call left work for the direct kernel": the launch's epoch in the second spare slot (every writer
-        // stores the same value).  The direct kernel leaves at once when the slot holds anything else -- an
-        // optimisation only: a stale or accidental match merely sends it through its per-panel checks.
-        if (!ok) info[npanels + 1].x = epoch;
+        info[p] = last >= first ? make_int2(first, last) : make_int2(1, 0);
+        const int c = mfma ? (window_ok ? PANEL_MFMA_W : PANEL_MFMA_D) : (window_ok ? PANEL_WINDOW : PANEL_DIRECT);
+        cls[p] = c;
+        // the middle panel's column span: the direct kernels take it as the band width of the matrix when they choose
+        // their panel -> XCD map (one writer)
+        if (p == npanels / 2) tail[TAIL_BAND] = last >= first ? last - first + 1 : 0;
+        // "this call left work for the direct kernel": the launch's epoch (every writer stores the same value).  The
+        // direct kernel leaves at once when the slot holds anything else -- an optimisation only: a stale or
+        // accidental match merely sends it through its per-panel checks.
+        if (c == PANEL_DIRECT || c == PANEL_MFMA_D) tail[TAIL_DIRECT_EPOCH] = epoch;
+        if (c == PANEL_MFMA_W || c == PANEL_MFMA_D) tail[TAIL_MFMA_EPOCH] = epoch;
     }
 }
 __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
                                                              const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx, int max_row_len,
-                                                             float min_density, int2 *__restrict__ info, int epoch)
+                                                             float min_density, float mfma_min_fill,
+                                                             int *__restrict__ tail, int2 *__restrict__ info,
+                                                             int *__restrict__ cls, int epoch)
 {
+    __shared__ unsigned bitmap[4][MFMA_BITMAP_WORDS];
     classify_panel(blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx, max_row_len,
-                   min_density, info, epoch);
+                   min_density, mfma_min_fill, tail, info, cls, epoch, bitmap[threadIdx.x >> 6]);
 }
 // Stage 1 and the panel classifier in one launch (the fused C-ABI entry: both depend only on the call's inputs, and
-// the classifier's few dependent loads hide behind the staging traffic): the first ceil(npanels / 4) workgroups
+// the classifier's dependent loads hide behind the staging traffic): the first ceil(npanels / 4) workgroups
 // (grid.y == 0 only) classify four panels each, the stage_blocks x grid.y behind them transpose B.
 __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64_t n, const double *__restrict__ B,
                                                             int64_t ldb, double *__restrict__ Bt, int64_t ldbt,
                                                             int stage_blocks, int rows, int npanels, int panel_rows,
                                                             const int *__restrict__ rowptr,
                                                             const int *__restrict__ colidx, int max_row_len,
-                                                            float min_density, int2 *__restrict__ info, int epoch)
+                                                            float min_density, float mfma_min_fill,
+                                                            int *__restrict__ tail, int2 *__restrict__ info,
+                                                            int *__restrict__ cls, int epoch)
 {
+    // a workgroup either transposes (tile) or classifies (bitmaps): one LDS area serves both
+    static_assert(sizeof(double) * 64 * (STAGE_K + 1) >= sizeof(unsigned) * 4 * MFMA_BITMAP_WORDS, "LDS area");
     __shared__ double tile[64][STAGE_K + 1];
     // the classifier's workgroups come first in the grid: their chain of dependent loads starts at once and ends
     // under the staging traffic (placed last they stuck out by ~3 us)
     const int cblocks = (npanels + 3) / 4;
     if ((int)blockIdx.x >= cblocks) {
         stage_tile(tile, (int64_t)((int)blockIdx.x - cblocks) * STAGE_K, (int64_t)blockIdx.y * 64, cols, n, B, ldb, Bt,
-                   ldbt);
+                   ldbt, tail, epoch);
     } else if (blockIdx.y == 0) {
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
-                       max_row_len, min_density, info, epoch);
+                       max_row_len, min_density, mfma_min_fill, tail, info, cls, epoch,
+                       reinterpret_cast<unsigned *>(&tile[0][0]) + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
     }
 }
-// column span of a classified panel (0 for an empty one)
-__device__ __forceinline__ int panel_span(int2 v)
+// which kernel computes panel p (cls == nullptr: no classifier ran, the direct kernel computes everything)
+__device__ __forceinline__ bool b_nonfinite(const int *__restrict__ tail)
 {
-    if (v.x >= 0) return v.y >= v.x ? v.y - v.x + 1 : 0;
-    return (-2 - v.y) - (-1 - v.x) + 1;
+    return tail[TAIL_NONFINITE] == tail[TAIL_STAGE_EPOCH];
+}
+__device__ __forceinline__ bool owns_direct(const int *__restrict__ tail, const int *__restrict__ cls, int p)
+{
+    const int c = cls[p];
+    return c == PANEL_DIRECT || (c == PANEL_MFMA_D && b_nonfinite(tail));
+}
+__device__ __forceinline__ bool owns_window(const int *__restrict__ tail, const int *__restrict__ cls, int p)
+{
+    const int c = cls[p];
+    return c == PANEL_WINDOW || (c == PANEL_MFMA_W && b_nonfinite(tail));
 }
 
 typedef int sblas_rsrc_t __attribute__((ext_vector_type(4)));
@@ -376,7 +435,8 @@ template <int G>
 __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int panel_rows, int nnz)
+    double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int2 *__restrict__ info,
+    const int *__restrict__ cls, int panel_rows, int nnz)
 {
     constexpr int RW = 4 * G, RMAX = 16 * RW;
     static_assert(G == 2 || G == 3, "two or three groups per wave (the counted vmcnt waits are 4 G)");
@@ -386,8 +446,8 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     int *sm_i = reinterpret_cast<int *>(smem + 2 * W2_TILE + 64); // [0] = bad
 
     const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    if (!owns_window(tail, cls, panel)) return; // another kernel owns this panel
     const int2 span = info[panel];
-    if (span.x > span.y) return; // the direct kernel owns this panel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -632,8 +692,8 @@ template <int GROUPS>
 __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave,
-    int epoch)
+    double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
+    int info_panel_rows, int interleave, int epoch)
 {
     static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "lane groups of 64, 32 or 16 lanes");
     constexpr int TILE_COLS = 128 / GROUPS;
@@ -642,7 +702,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
     // every panel windowed (the bench matrix): one scalar load of one shared address and out, instead of two
     // dependent loads per workgroup (4500 workgroups of early exits took 16 us of a 340 us step)
-    if (info != nullptr && info[(rows + info_panel_rows - 1) / info_panel_rows + 1].x != epoch) return;
+    if (cls != nullptr && tail[TAIL_DIRECT_EPOCH] != epoch) return;
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
@@ -650,8 +710,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     // (`interleave` < 0: decide from the column span the classifier recorded -- a band of B rows wider than 16 MB)
     if (interleave < 0) {
         interleave = 0;
-        if (info != nullptr) { // one value for every workgroup: the middle panel's span, left by the classifier
-            const int band = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+        if (cls != nullptr) { // one value for every workgroup: the middle panel's span, left by the classifier
+            const int band = tail[TAIL_BAND];
             interleave = (long long)band * (TILE_COLS * 8) > (16ll << 20);
         }
     }
@@ -662,9 +722,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int row = row0 + wave;
     // rows of panels that the windowed kernel owns are skipped (wave-uniform: one row per wave)
     bool mine = row < rows;
-    if (info && mine) {
-        const int2 span = info[row / info_panel_rows];
-        mine = span.x > span.y;
+    if (cls && mine) {
+        mine = owns_direct(tail, cls, row / info_panel_rows);
         if (mine && lane == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
     }
     const int sub = lane & 15;
@@ -816,12 +875,12 @@ constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
 __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
-    double *__restrict__ C, int64_t ldc, const int2 *__restrict__ info, int info_panel_rows, int interleave,
-    int epoch)
+    double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
+    int info_panel_rows, int interleave, int epoch)
 {
     __shared__ double ctile[64][ROWS_PANEL + 1];
     __shared__ int row_mine[ROWS_PANEL];
-    if (info != nullptr && info[(rows + info_panel_rows - 1) / info_panel_rows + 1].x != epoch) return; // nothing direct
+    if (cls != nullptr && tail[TAIL_DIRECT_EPOCH] != epoch) return; // nothing direct
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     const int k = lane & 15, q = lane >> 4;
@@ -829,8 +888,8 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     if (col0 >= n) return; // a padding tile of ldbt (uniform over the workgroup)
     if (interleave < 0) {
         interleave = 0;
-        if (info != nullptr) {
-            const int band = info[(rows + info_panel_rows - 1) / info_panel_rows].x;
+        if (cls != nullptr) {
+            const int band = tail[TAIL_BAND];
             interleave = (long long)band * 512 > (16ll << 20);
         }
     }
@@ -838,9 +897,8 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     const int rr = wave * 4 + q;
     const int row = row0 + rr;
     bool mine = row < rows;
-    if (info && mine) {
-        const int2 span = info[row / info_panel_rows];
-        mine = span.x > span.y;
+    if (cls && mine) {
+        mine = owns_direct(tail, cls, row / info_panel_rows);
         if (mine && k == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
     }
     const unsigned ldb8 = (unsigned)ldbt * 8u;
@@ -1070,13 +1128,6 @@ static inline unsigned capped_grid(int64_t work_items, int per_block)
     return (unsigned)b;
 }
 
-hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
-                                    double *Bt, int64_t ldbt)
-{
-    dim3 grid((unsigned)((cols + 1 + STAGE_K - 1) / STAGE_K), (unsigned)((ldbt + 63) / 64));
-    hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt);
-    return hipGetLastError();
-}
 
 // compute units of the current device (queried once per device)
 static int compute_units()
@@ -1153,6 +1204,7 @@ static void options_parse(Options &o)
         o.panel_rows = atoi(e);
         o.panel_groups = strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0;
     }
+    if ((e = getenv("SBLAS_MFMA_MIN_FILL")) && *e) o.mfma_min_fill = (float)atof(e);
     if ((e = getenv("SBLAS_TUNE")) && *e) { /* "a,b,c,d": free integers for kernel experiments */
         sscanf(e, "%d,%d,%d,%d", &o.tune[0], &o.tune[1], &o.tune[2], &o.tune[3]);
     }
@@ -1225,21 +1277,62 @@ static void gen6_plan(int rows, int &info_rows, int &gen6_g)
     }
 }
 
-static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts (see classify_panel)
+static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts and one staging pass (see classify_panel)
 
-// Stage 1 + classifier of the default (sixth-generation) path in one launch; the epoch goes to launch_spmm_rowpanel.
+// The workspace behind the staging copy (kernels.h): header ints, one span per panel, one class per panel.
+struct Tail {
+    int *hdr;
+    int2 *info;
+    int *cls;
+};
+static Tail tail_of(const double *Bt, int64_t cols, int64_t ldbt, int rows)
+{
+    Tail t;
+    t.hdr = reinterpret_cast<int *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
+    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + SPMM_MIN_PANEL_ROWS - 1) / SPMM_MIN_PANEL_ROWS;
+    t.info = reinterpret_cast<int2 *>(t.hdr + TAIL_HDR);
+    t.cls = reinterpret_cast<int *>(t.info + panels);
+    return t;
+}
+size_t workspace_tail_bytes(int64_t rows)
+{
+    const size_t panels = ((size_t)(rows > 0 ? rows : 0) + SPMM_MIN_PANEL_ROWS - 1) / SPMM_MIN_PANEL_ROWS;
+    return (TAIL_HDR * sizeof(int) + panels * (sizeof(int2) + sizeof(int)) + 31) / 16 * 16; // whole 16-byte units
+}
+// block fill from which a panel goes to the matrix cores (fp64 MFMA and fp64 vector FMA have the same peak on gfx950,
+// so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/mfma_fill_sweep.py
+static float mfma_min_fill(int variant)
+{
+    if (variant == SPMM_VARIANT_MFMA) return 0.0f;
+    if (variant == SPMM_VARIANT_NO_MFMA) return 2.0f;
+    return options().mfma_min_fill;
+}
+
+hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
+                                    double *Bt, int64_t ldbt)
+{
+    dim3 grid((unsigned)((cols + 1 + STAGE_K - 1) / STAGE_K), (unsigned)((ldbt + 63) / 64));
+    int *hdr = reinterpret_cast<int *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
+    hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, hdr,
+                       g_epoch.fetch_add(1, std::memory_order_relaxed));
+    return hipGetLastError();
+}
+
+// Stage 1 + classifier of the default path in one launch; the epoch goes to launch_spmm_rowpanel.
 hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
-                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int *epoch_out)
+                                 int64_t ldbt, int rows, const int *rowptr, const int *colidx, int variant,
+                                 int *epoch_out)
 {
     int info_rows = 0, g = 2;
     gen6_plan(rows, info_rows, g);
     const int np = (rows + info_rows - 1) / info_rows;
     const int stage_blocks = (int)((cols + 1 + STAGE_K - 1) / STAGE_K);
     const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
-    int2 *winfo = reinterpret_cast<int2 *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
+    const Tail t = tail_of(Bt, cols, ldbt, rows);
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, winfo, epoch);
+                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant), t.hdr, t.info,
+                       t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
 }
@@ -1251,41 +1344,47 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
     const Options &opt = options();
     const double avg_row = rows > 0 ? (double)nnz / (double)rows : 0.0;
     if (ldbt >= 64) {
-        const int2 *info = nullptr;
+        const Tail t = tail_of(Bt, cols, ldbt, rows);
+        const int *cls = nullptr;
         int info_rows = 1;
-        // pre_epoch != 0: launch_stage_classify has classified the panels already (default variant only)
+        // pre_epoch != 0: launch_stage_classify has classified the panels already
         const bool classified = variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS;
         const bool preclassified = pre_epoch != 0 && classified;
         const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         if (classified) {
-            // 1. classify row panels; 2. LDS-tiled kernel on the qualifying ones; 3. direct kernel on the rest
+            // 1. classify row panels; 2. LDS-tiled kernel and matrix-core kernel on the panels that qualify;
+            // 3. direct kernel on the rest
             int gen6_g = 2;
             gen6_plan(rows, info_rows, gen6_g);
-            int2 *winfo = reinterpret_cast<int2 *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
             const int np = (rows + info_rows - 1) / info_rows;
             if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
                                    info_rows, rowptr, colidx, /* 32-bit buffer offsets inside a wave's rows */ 1 << 24,
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
-                                   (float)info_rows / 16.0f, winfo, epoch);
+                                   (float)info_rows / 16.0f, mfma_min_fill(variant), t.hdr, t.info, t.cls, epoch);
             dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
             if (gen6_g == 3) {
                 raise_dynamic_lds((const void *)spmm_window6_kernel<3>, W2_LDS_BYTES);
                 hipLaunchKernelGGL(spmm_window6_kernel<3>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, info_rows, (int)nnz);
+                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz);
             } else {
                 raise_dynamic_lds((const void *)spmm_window6_kernel<2>, W2_LDS_BYTES);
                 hipLaunchKernelGGL(spmm_window6_kernel<2>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, winfo, info_rows, (int)nnz);
+                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz);
             }
             if (kev) {
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;
             }
-            info = winfo;
+            if (mfma_min_fill(variant) <= 1.0f) {
+                const hipError_t e = launch_spmm_mfma(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc,
+                                                      t.info, t.hdr, t.cls, info_rows, np, epoch, panel_stats_device());
+                if (e != hipSuccess) return e;
+            }
+            cls = t.cls;
         }
         const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
         // 128-column tiles: one workgroup per CU through unused dynamic LDS (Queen-like rows at N = 256: +13 %, banded
@@ -1296,23 +1395,23 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             // short rows: four rows per wave
             const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
             hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
-                               cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info, info_rows, interleave,
-                               epoch);
+                               cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
+                               interleave, epoch);
         } else if (ldbt == 64 && n <= 32) {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<4>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
-                               rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info,
+                               rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls,
                                info_rows, interleave, epoch);
         } else if (ldbt == 64) {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<2>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<2>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
-                               rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, info,
+                               rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls,
                                info_rows, interleave, epoch);
         } else {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<1>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, dim3((unsigned)wide_panels, (unsigned)(ldbt / 128)),
                                dim3(WIDE_WAVES * 64), pad, s, rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n,
-                               alpha, beta, C, ldc, info, info_rows, interleave, epoch);
+                               alpha, beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
         }
     } else {
         const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
@@ -1334,6 +1433,20 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         }
     }
     return hipGetLastError();
+}
+
+// device address of the panel census (the matrix-core kernel lives in another translation unit)
+unsigned long long *panel_stats_device()
+{
+    static unsigned long long *ptr[16] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!ptr[dev]) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_panel_stats)) != hipSuccess) return nullptr;
+        ptr[dev] = static_cast<unsigned long long *>(p);
+    }
+    return ptr[dev];
 }
 
 hipError_t panel_stats(unsigned long long out[4], bool reset)

@@ -303,3 +303,10 @@ def merge_rowblocks(comm, M, N, starts, nrows, partial, gather, alpha, beta, Cs,
     check(lib().sblas_hip_merge_rowblocks_f64(comm, M, N, st, nr, _ptr_array(partial, "partial", allow_none=True), ga,
                                               alpha, beta, _ptr_array(Cs, "C"), ldc, _stream_array(streams)),
           "sblas_hip_merge_rowblocks_f64")
+
+
+def panel_census(reset=True):
+    """dict(windowed, direct, fallback, mfma): row panels per stage-2 kernel since the last reset."""
+    out = (C.c_uint64 * 4)()
+    check(lib().sblas_hip_debug_spmm_panel_stats(out, 1 if reset else 0), "sblas_hip_debug_spmm_panel_stats")
+    return dict(windowed=int(out[0]), direct=int(out[1]), fallback=int(out[2]), mfma=int(out[3]))

@@ -105,3 +105,116 @@ def random_csr(rows, cols, avg_nnz, seed=SEED, sorted_rows=False, empty_every=0,
             colidx[rowptr[r]:rowptr[r + 1]].sort()
     val = rng.random(nnz) * 2.0 - 1.0
     return rowptr.astype(np.int32), colidx, val
+
+
+def block_structured(rows, nnz_per_row=399, half_band=2000, block_rows=16, block_cols=4, fill=0.6, seed=SEED):
+    """nd24k-like rows (same row length and band as nd24k_like) whose nonzeros sit in dense sub-blocks, the shape
+    supernodal / multi-dof FEM matrices have and the uniform stand-in lacks: the matrix is cut into block_rows x
+    block_cols aligned blocks, every block row (16 matrix rows) picks the block columns it uses inside its band, and
+    every (row, column) position of a picked block holds a nonzero with probability `fill`.  The number of picked
+    blocks is chosen so that rows average nnz_per_row.  Columns ascending per row, values U[0, 1)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    nbr = (rows + block_rows - 1) // block_rows
+    per_blockrow = max(1, int(round(nnz_per_row / (block_cols * fill))))
+    counts = np.zeros(rows, np.int64)
+    cols_list = []
+    for br in range(nbr):
+        r0, r1 = br * block_rows, min(rows, (br + 1) * block_rows)
+        lo = max(0, r0 - half_band) // block_cols
+        hi = min(rows, r1 + half_band) // block_cols            # exclusive block-column bound
+        picked = np.sort(rng.choice(np.arange(lo, max(hi, lo + 1)), min(per_blockrow, max(hi - lo, 1)), replace=False))
+        # positions: (r1 - r0) x (picked * block_cols + 0..block_cols-1), kept with probability `fill`
+        colgrid = (picked[:, None] * block_cols + np.arange(block_cols)[None, :]).reshape(-1)
+        colgrid = colgrid[colgrid < rows]
+        keep = rng.random((r1 - r0, colgrid.size)) < fill
+        for i in range(r1 - r0):
+            c = colgrid[keep[i]]
+            if c.size == 0:
+                c = colgrid[:1]
+            cols_list.append(c.astype(np.int32))
+            counts[r0 + i] = c.size
+    rowptr = np.zeros(rows + 1, np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    colidx = np.concatenate(cols_list)
+    val = rng.random(colidx.size)
+    return rowptr.astype(np.int32), colidx, val
+
+
+def queen_like_grid(rows, seed=SEED, half_band=50000, keep=0.93):
+    """Queen_4147-like rows with the locality a 3-D FEM numbering has (queen_like() scatters its 40 offsets uniformly,
+    which no mesh ordering does): nodes of a structured nx x ny x nz grid numbered x-fastest, 3 dofs per node, every
+    node coupled to its 27 grid neighbours (each kept with probability `keep`, the diagonal always), i.e. up to
+    27 x 3 = 81 columns per row in nine runs of nine consecutive columns; the plane size nx*ny is chosen so that
+    the farthest neighbour sits `half_band` rows away (3 * (nx*ny + nx + 1) ~ half_band).  `rows` is rounded down
+    to whole nodes.  Columns ascending, duplicate-free, values U[-1, 1)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    nodes = max(rows // 3, 8)
+    plane = max(4, min(half_band // 3, nodes // 3))
+    nx = max(2, int(np.sqrt(plane)))
+    ny = max(2, plane // nx)
+    plane = nx * ny
+    nz = max(1, (nodes + plane - 1) // plane)
+    nodes = min(nodes, plane * nz)
+    rows = nodes * 3
+    n = np.arange(nodes, dtype=np.int64)
+    x, y, z = n % nx, (n // nx) % ny, n // plane
+    cols_parts, cnt = [], np.zeros(nodes, np.int64)
+    offs = [(dx, dy, dz) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    nb = np.empty((nodes, 27), np.int64)
+    ok = np.empty((nodes, 27), bool)
+    for k, (dx, dy, dz) in enumerate(offs):
+        xx, yy, zz = x + dx, y + dy, z + dz
+        m = n + dx + nx * dy + plane * dz
+        ok[:, k] = (xx >= 0) & (xx < nx) & (yy >= 0) & (yy < ny) & (zz >= 0) & (m >= 0) & (m < nodes)
+        nb[:, k] = m
+    drop = rng.random((nodes, 27)) >= keep
+    drop[:, 13] = False                                           # the node itself stays
+    ok &= ~drop
+    per_node = ok.sum(1)
+    # rows of a node share its column set: 3 dofs x (neighbours x 3 dofs)
+    rowptr = np.zeros(rows + 1, np.int64)
+    np.cumsum(np.repeat(per_node * 3, 3), out=rowptr[1:])
+    colidx = np.empty(int(rowptr[-1]), np.int32)
+    flat_nb = nb[ok]                                              # neighbours in ascending order per node (offs is sorted)
+    node_start = np.zeros(nodes + 1, np.int64)
+    np.cumsum(per_node, out=node_start[1:])
+    c3 = (flat_nb[:, None] * 3 + np.arange(3)[None, :]).reshape(-1)   # columns of one row of each node, node after node
+    # scatter: row 3n+d gets the 3*per_node[n] columns of node n
+    starts = rowptr[:-1].reshape(nodes, 3)
+    lens = per_node * 3
+    src_start = node_start[:-1] * 3
+    idx_in = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(src_start, lens)
+    for d in range(3):
+        colidx[np.repeat(starts[:, d], lens) + idx_in] = c3
+    val = rng.random(colidx.size) * 2.0 - 1.0
+    return rowptr.astype(np.int32), colidx, val
+
+
+def powerlaw(rows, avg=3.0, max_len=5000, alpha=2.25, seed=SEED, cols=None):
+    """webbase-1M-like (the reference authors' own SpMV profiling input, profiling.sh:16,21): row lengths from a
+    truncated power law (most rows hold 1-3 nonzeros, a few hold thousands; mean ~avg, maximum max_len), columns uniform
+    over the matrix, ascending and duplicate-free inside a row, values U[-1, 1)."""
+    cols = rows if cols is None else cols
+    rng = np.random.Generator(np.random.MT19937(seed))
+    u = rng.random(rows)
+    # inverse CDF of a Pareto tail on [1, max_len]
+    a = alpha - 1.0
+    lens = np.floor((1.0 - u * (1.0 - max_len ** (-a))) ** (-1.0 / a)).astype(np.int64)
+    lens = np.clip(lens, 1, min(max_len, cols))
+    for _ in range(4):                                            # scale the body towards the requested mean, keep the tail
+        scale = avg / lens.mean()
+        if abs(scale - 1.0) < 0.02:
+            break
+        lens = np.clip(np.round(lens * np.where(lens < 64, scale, 1.0)).astype(np.int64), 1, min(max_len, cols))
+    lens[rng.integers(0, rows)] = min(max_len, cols)              # the maximum is always present
+    rowptr = np.zeros(rows + 1, np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colidx = rng.integers(0, cols, nnz).astype(np.int64)
+    # sort inside rows: key = row * cols + col
+    key = np.repeat(np.arange(rows, dtype=np.int64), lens) * cols + colidx
+    key.sort()
+    colidx = (key % cols).astype(np.int32)
+    # duplicates inside a row are legal CSR (the reference adds them up); leave them in
+    val = rng.random(nnz) * 2.0 - 1.0
+    return rowptr.astype(np.int32), colidx, val

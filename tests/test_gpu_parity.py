@@ -759,6 +759,106 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_e
     assert run(rp4, ci4, v4, rows, rows) == (10, 0, 0)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the matrix-core (MFMA) kernel: panels whose nonzeros sit in dense 16 x 4 sub-blocks
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 20, 64, 100, 128, 200])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma"])
+def test_spmm_mfma_block_structured(env, variant_env, variant, n):
+    """nd24k-like rows in dense sub-blocks (60 % fill): the classifier samples the block fill and sends the panels to
+    the fp64 MFMA kernel; `mfma` forces it for every panel, `nomfma` forbids it.  Within 1e-10 relative of the oracle
+    (observed: the MFMA adds a row's products in column order like the oracle's loop, zeros in between: <= 4e-16)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    rows = 1000
+    rp, ci, v = synth.block_structured(rows, nnz_per_row=150, half_band=400, fill=0.6)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(n)
+    B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    sblas.panel_census()
+    for alpha, beta in ((1.0, 1.0), (-0.5, 0.0)):
+        got = gpu_spmm(sblas, torch, dev, A, B, rows, n, alpha, beta, C0, rows)
+        ref = oracle.spmm(rows, rows, n, *A.h, B, C0.copy(), alpha, beta)
+        assert close(got, ref), (variant, n, np.abs(got - ref).max())
+    census = sblas.panel_census()
+    if n > 8:
+        assert (census["mfma"] > 0) == (variant != "nomfma"), census
+        if variant == "mfma":
+            assert census["windowed"] == 0 and census["direct"] == 0, census
+
+
+@pytest.mark.parametrize("kind", ["random_unsorted", "duplicates", "ragged_rect", "one_long_row", "wide_span"])
+def test_spmm_mfma_forced_on_any_matrix(env, variant_env, kind):
+    """The MFMA kernel assumes nothing about the matrix (it merges the rows of a 16-row group chunk by chunk; LDS
+    atomics add duplicates): forced onto unsorted rows, duplicate columns, empty rows, a 5000-entry row, a rectangular
+    matrix whose rows are not a multiple of 16 and rows that span 100 000 columns."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env("mfma")
+    n = 64
+    if kind == "random_unsorted":
+        rows, cols = 333, 777
+        rp, ci, v = synth.random_csr(rows, cols, 20, seed=3, empty_every=7)
+    elif kind == "duplicates":
+        rows, cols = 200, 64
+        rp, ci, v = synth.random_csr(rows, cols, 90, seed=4, sorted_rows=True)      # 90 draws from 64 columns
+    elif kind == "ragged_rect":
+        rows, cols = 1003, 5
+        rp, ci, v = synth.random_csr(rows, cols, 3, seed=5, sorted_rows=True, empty_every=4)
+    elif kind == "one_long_row":
+        rows, cols = 100, 3000
+        rp, ci, v = synth.random_csr(rows, cols, 4, seed=6, sorted_rows=True, long_row=(50, 5000))
+    else:
+        rows = cols = 150000
+        rp, ci, v = synth.queen_like_grid(rows)
+        rows = cols = len(rp) - 1
+    A = Dev(torch, dev, rp, ci, v, cols)
+    rng = np.random.default_rng(1)
+    B, C0 = rng.standard_normal(cols * n), rng.standard_normal(rows * n)
+    sblas.panel_census()
+    got = gpu_spmm(sblas, torch, dev, A, B, cols, n, 2.0, -1.0, C0, rows)
+    census = sblas.panel_census()
+    if kind == "wide_span":
+        ref = C0.copy()
+        for r0 in (0, rows // 2, rows - 64):
+            oracle.spmm_rows(r0, r0 + 64, rows, cols, n, *A.h, B, ref, 2.0, -1.0)
+            assert close(got.reshape(n, rows)[:, r0:r0 + 64], ref.reshape(n, rows)[:, r0:r0 + 64]), r0
+    else:
+        ref = oracle.spmm(rows, cols, n, *A.h, B, C0.copy(), 2.0, -1.0)
+        assert close(got, ref), (kind, np.abs(got - ref).max())
+    if kind in ("duplicates", "ragged_rect", "one_long_row", "wide_span"):      # sorted rows: every panel took the matrix cores
+        assert census["mfma"] > 0 and census["direct"] == 0 and census["windowed"] == 0, census
+
+
+def test_spmm_mfma_leaves_nonfinite_b_to_the_vector_kernels(env, variant_env):
+    """0 * Inf from a block's zero fill would reach rows that never refer to that row of B, so a staging pass that met
+    a non-finite value hands the MFMA panels to the vector kernels: rows that do not refer to the Inf row stay finite
+    and exact, rows that do carry the oracle's Inf / NaN."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env("mfma")
+    rows, n = 640, 64
+    rp, ci, v = synth.block_structured(rows, nnz_per_row=100, half_band=300, fill=0.7)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(2)
+    Bh, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
+    Bh.reshape(n, rows)[3, int(ci[rp[100]])] = np.inf            # one Inf in a referenced row of B
+    sblas.panel_census()
+    got = gpu_spmm(sblas, torch, dev, A, Bh, rows, n, 1.0, 1.0, C0, rows)
+    census = sblas.panel_census()
+    ref = oracle.spmm(rows, rows, n, *A.h, Bh, C0.copy(), 1.0, 1.0)
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all()
+    assert close(got[fin], ref[fin])
+    assert census["mfma"] == 0 and census["windowed"] + census["direct"] > 0, census
+    # the same workspace with a finite B afterwards: back on the matrix cores
+    Bh2 = rng.standard_normal(rows * n)
+    got2 = gpu_spmm(sblas, torch, dev, A, Bh2, rows, n, 1.0, 1.0, C0, rows)
+    assert close(got2, oracle.spmm(rows, rows, n, *A.h, Bh2, C0.copy(), 1.0, 1.0))
+    assert sblas.panel_census()["mfma"] > 0
+
+
 @pytest.fixture
 def spmv_variant_env():
     yield from _env_switch("SBLAS_SPMV_VARIANT")
