@@ -164,6 +164,10 @@ int64_t sblas_partition_nnz(const int32_t *rowptr, int32_t rows, int32_t nnz, in
 int sblas_partition_dense(int64_t first_order, int n_gpu, int i_gpu,
                           int64_t *offset, int64_t *dim);
 
+/* Dense initialiser of the reference's DenseMatrix(h, w, order) / DenseVector(len) constructors (matrix.h:519-528,
+ * :663-672; utility.h:197; config.h:23 seed 211): srand(seed), then rand() / RAND_MAX in storage order (host memory). */
+int sblas_host_fill_rand0to1(double *dst, int64_t count, unsigned seed);
+
 /* ---------------------------------------------------------------------------------------
  * MatrixMarket -> CSR (host).  Same observable result as mmio_info / mmio_data
  * (mmio_highlevel.h:7-127, :130-281): file order preserved inside a row, symmetric/hermitian

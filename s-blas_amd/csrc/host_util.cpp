@@ -54,6 +54,17 @@ extern "C" int64_t sblas_partition_nnz(const int32_t *rowptr, int32_t rows, int3
     return num;
 }
 
+// The dense initialiser of the reference's DenseMatrix / DenseVector constructors (matrix.h:519-528, :663-672):
+// srand(seed) and rand() / RAND_MAX in storage order -- the C library's generator, so callers outside C++ (bench.py)
+// can build the very B the reference's drivers multiply.  Not re-entrant (global libc state), like the reference.
+extern "C" int sblas_host_fill_rand0to1(double *dst, int64_t count, unsigned seed)
+{
+    if (count < 0 || (count > 0 && !dst)) return SBLAS_E_INVALID;
+    srand(seed);
+    for (int64_t i = 0; i < count; ++i) dst[i] = (double)rand() / (double)RAND_MAX;
+    return SBLAS_OK;
+}
+
 extern "C" int sblas_partition_dense(int64_t first_order, int n_gpu, int i_gpu, int64_t *offset, int64_t *dim)
 {
     if (first_order < 0 || n_gpu <= 0 || i_gpu < 0 || i_gpu >= n_gpu || !offset || !dim) return SBLAS_E_INVALID;

@@ -24,7 +24,7 @@ EXPORTS = [
     "sblas_hip_comm_get", "sblas_hip_comm_release_all", "sblas_hip_allreduce_sum_f64",
     "sblas_hip_merge_rowblocks_f64", "sblas_hip_merge_rowblocks_local_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
-    "sblas_mm_read_info", "sblas_mm_read_csr",
+    "sblas_mm_read_info", "sblas_mm_read_csr", "sblas_host_fill_rand0to1",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
     L.sblas_mm_read_info.argtypes = [C.c_char_p] + [C.POINTER(i32)] * 4
     L.sblas_mm_read_csr.restype = C.c_int
     L.sblas_mm_read_csr.argtypes = [C.c_char_p, vp, vp, vp]
+    L.sblas_host_fill_rand0to1.restype = C.c_int
+    L.sblas_host_fill_rand0to1.argtypes = [vp, i64, C.c_uint]
     _lib = L
     return L
 
@@ -117,6 +119,13 @@ def read_mtx(path):
     val = np.zeros(max(z.value, 1), np.float64)
     check(L.sblas_mm_read_csr(os.fsencode(path), rowptr.ctypes.data, colidx.ctypes.data, val.ctypes.data), "sblas_mm_read_csr")
     return r.value, c.value, z.value, s.value, rowptr, colidx[:z.value], val[:z.value]
+
+
+def rand0to1(count, seed=211):
+    """The reference's dense initialiser (DenseMatrix ctor, matrix.h:519-528): srand(seed), rand() / RAND_MAX."""
+    out = np.empty(int(count), np.float64)
+    check(lib().sblas_host_fill_rand0to1(out.ctypes.data, int(count), seed), "sblas_host_fill_rand0to1")
+    return out
 
 
 def find_row_of_nnz(rowptr, nnz_idx):

@@ -235,3 +235,15 @@ def test_synthetic_generators(sblas):
     assert (ci == ci2).all() and (v == v2).all()          # deterministic
     rp, ci, v = synth.random_csr(100, 50, 7, empty_every=10, long_row=(3, 300))
     assert rp[4] - rp[3] == 300 and rp[1] - rp[0] == 0 and ci.max() < 50
+
+
+def test_host_rand0to1_is_the_reference_initialiser(sblas, oracle):
+    """sblas_host_fill_rand0to1 = DenseMatrix's constructor fill (matrix.h:519-528): the golden B values the survey
+    captured from the reference, and bit-identical to the oracle's restatement."""
+    import json, os
+    from conftest import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "ash85_golden.json")))["spmm_n64_a1_b1"]
+    B = sblas.rand0to1(85 * 64)
+    assert B[0] == g["B_first"] and B[1] == g["B_second"] and B[-1] == g["B_last"]
+    assert (B == oracle.rand0to1(85 * 64)).all()
+    assert len(sblas.rand0to1(0)) == 0

@@ -2,9 +2,9 @@
 """Copy the rocprofv3 summaries written by tools/profile.sh (gpurun_out/prof) into profiles/ (tracked) and merge the
 FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_hbm_traffic.json, the file bench.py reads `roofline.traffic`
 from.  Usage: python tools/collect_profiles.py [round-prefix, default r01]"""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = "gpurun_out/prof", "profiles"
 os.makedirs(dst, exist_ok=True)
 for op in ("spmm", "spmv"):
@@ -44,6 +44,14 @@ CORR = ("gfx950: FETCH_SIZE counts 64 B per 128 B request -> read bytes = 2*FETC
         "WRITE_SIZE exact; unit KiB")
 
 
+def source_sha16():
+    """the fingerprint bench.py compares: a traffic figure is only quoted for the kernel sources it was measured on"""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob("s-blas_amd/csrc/*")):
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def merge(prefix, path, command, workload):
     per = collections.defaultdict(dict)
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -58,6 +66,7 @@ def merge(prefix, path, command, workload):
         return
     doc = json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
     doc["command"] = command
+    doc["source_sha16"] = source_sha16()
     doc.setdefault("workload", workload)
     for k, v in per.items():
         if "sblas::" not in k or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:

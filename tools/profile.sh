@@ -4,13 +4,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/spmm -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 > $OUT/spmm_bench.json 2> $OUT/spmm.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/spmm -- python3 $R/bench.py --steps 50 --warmup 5 --cpu-seconds 0 --no-extras > $OUT/spmm_bench.json 2> $OUT/spmm.err
 echo "spmm rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/spmv -- python3 $R/bench.py --op spmv --steps 50 --warmup 5 > $OUT/spmv_bench.json 2> $OUT/spmv.err
 echo "spmv rc=$?"
 # HBM traffic counters, one pass each (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-extras > /dev/null 2> $OUT/pmc_$c.err
   echo "$c rc=$?"
 done
 for c in FETCH_SIZE WRITE_SIZE; do
