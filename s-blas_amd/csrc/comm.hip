@@ -88,24 +88,36 @@ extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
             if (key[i] != key[j]) all_same = false;
             else all_distinct = false;
         }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = SBLAS_OK;
     if (n_gpu == 1) {
         // a single rank: the sum over ranks is the identity, no communicator needed
     } else if (all_same) {
         set->one_device = true;
-        int prev = 0;
-        (void)hipGetDevice(&prev);
-        if (hipSetDevice(key[0]) != hipSuccess) return SBLAS_E_HIP;
-        set->events.resize(n_gpu);
-        for (int i = 0; i < n_gpu; ++i)
-            if (hipEventCreateWithFlags(&set->events[i], hipEventDisableTiming) != hipSuccess) return SBLAS_E_HIP;
-        (void)hipSetDevice(prev);
+        if (hipSetDevice(key[0]) != hipSuccess) rc = SBLAS_E_HIP;
+        for (int i = 0; i < n_gpu && rc == SBLAS_OK; ++i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = SBLAS_E_HIP;
+            else set->events.push_back(e);
+        }
     } else if (all_distinct) {
         Rccl &r = rccl();
-        if (!r.ok) return SBLAS_E_RCCL;
-        set->comms.resize(n_gpu);
-        if (r.CommInitAll(set->comms.data(), n_gpu, key.data()) != 0) return SBLAS_E_RCCL;
+        if (!r.ok) rc = SBLAS_E_RCCL;
+        if (rc == SBLAS_OK) {
+            set->comms.assign(n_gpu, nullptr);
+            if (r.CommInitAll(set->comms.data(), n_gpu, key.data()) != 0) {
+                set->comms.clear();
+                rc = SBLAS_E_RCCL;
+            }
+        }
     } else {
-        return SBLAS_E_INVALID; // partially oversubscribed layouts are not supported
+        rc = SBLAS_E_INVALID; // partially oversubscribed layouts are not supported
+    }
+    (void)hipSetDevice(prev); // every path leaves the caller's device current
+    if (rc != SBLAS_OK) {     // nothing half-built stays behind
+        for (auto e : set->events) (void)hipEventDestroy(e);
+        return rc;
     }
     *comm_out = set.get();
     g_sets.emplace(key, std::move(set));

@@ -32,7 +32,7 @@ enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pas
        TAIL_MFMA_EPOCH = 4,   // epoch of the classifier run that gave panels to the matrix-core kernel
        TAIL_HDR = 16 };
 enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3 };
-constexpr int MFMA_MAX_WAVES = 9; // 16 rows per wave: panels of up to 144 rows
+constexpr int MFMA_MAX_WAVES = 8; // 16 rows per wave: panels of up to 128 rows (taller panels never take the MFMA kernel)
 size_t workspace_tail_bytes(int64_t rows);
 unsigned long long *panel_stats_device();
 hipError_t launch_spmm_mfma(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx, const double *val,
@@ -51,7 +51,7 @@ struct Options {
     double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
     int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE
-    float mfma_min_fill = 0.40f;          // SBLAS_MFMA_MIN_FILL: block fill from which a panel takes the MFMA kernel
+    float mfma_min_fill = -1.0f;          // SBLAS_MFMA_MIN_FILL: block fill from which a panel takes the MFMA kernel (< 0: built-in rule)
 };
 const Options &options();
 void options_reload();

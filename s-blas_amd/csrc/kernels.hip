@@ -213,19 +213,43 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
     }
     const bool sane = last >= first && first >= 0 && last < cols; // (first / last of sorted rows; the kernels re-check)
     const bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1);
-    // block fill of the first 16 rows: their entries are one contiguous run of the CSR arrays
+    // Matrix cores?  The fill of the 16 x 4 blocks a 16-row group touches, sampled on the panel's first 16 rows.  A
+    // cheap filter first, on the panel's first row alone: the block fill cannot exceed a row's own fill of the 4-column
+    // blocks it touches (entries / (4 x distinct blocks)), and that takes one pass over one row.
     bool mfma = false;
     if (sane && mfma_min_fill <= 1.0f) {
         const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
-        const int e0 = rowptr[r0], e1 = rowptr[r1];
+        // (the longest of the first 16 rows: the first row itself may be empty)
+        int slen = 0, srow = r0;
+        if (r0 + lane < r1) slen = rowptr[r0 + lane + 1] - rowptr[r0 + lane];
+        int key = (slen << 4) | (15 - (lane & 15)); // longest row, lowest index first
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) key = max(key, __shfl_xor(key, m, WAVE));
+        srow = r0 + 15 - (__builtin_amdgcn_readfirstlane(key) & 15);
+        srow = min(srow, r1 - 1);
+        const int a0 = rowptr[srow], b0 = rowptr[srow + 1];
+        int runs = 0;
+        for (int e = a0 + lane; e < b0; e += WAVE) {
+            const int c = colidx[e], cp = e > a0 ? colidx[e - 1] : -8;
+            runs += (c >> 2) != (cp >> 2);
+        }
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) runs += __shfl_xor(runs, m, WAVE);
+        const bool candidate = b0 > a0 && (float)(b0 - a0) >= mfma_min_fill * 4.0f * (float)runs;
+        const int e0 = rowptr[r0], e1 = rowptr[r1]; // the 16 rows' entries are one contiguous run of the CSR arrays
         const int blo = first >> 2;
-        if (e1 > e0 && ((last >> 2) - blo) < MFMA_BITMAP_WORDS * 32) {
+        if (candidate && ((last >> 2) - blo) < MFMA_BITMAP_WORDS * 32) {
             for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) bitmap[w] = 0u;
             bool in_range = true;
-            for (int e = e0 + lane; e < e1; e += WAVE) {
-                const unsigned blk = (unsigned)((colidx[e] >> 2) - blo);
-                if (blk < (unsigned)(MFMA_BITMAP_WORDS * 32)) atomicOr(&bitmap[blk >> 5], 1u << (blk & 31));
-                else in_range = false; // an unsorted row's entry outside [first, last]: not a candidate
+            for (int e = e0 + lane; e < e1; e += 8 * WAVE) { // eight loads in flight per lane
+                unsigned blk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) blk[u] = (unsigned)((colidx[min(e + u * WAVE, e1 - 1)] >> 2) - blo);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (blk[u] < (unsigned)(MFMA_BITMAP_WORDS * 32)) atomicOr(&bitmap[blk[u] >> 5], 1u << (blk[u] & 31));
+                    else in_range = false; // an unsorted row's entry outside [first, last]: not a candidate
+                }
             }
             int nblk = 0;
             for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) nblk += __popc(bitmap[w]);
@@ -1301,11 +1325,18 @@ size_t workspace_tail_bytes(int64_t rows)
 }
 // block fill from which a panel goes to the matrix cores (fp64 MFMA and fp64 vector FMA have the same peak on gfx950,
 // so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/mfma_fill_sweep.py
-static float mfma_min_fill(int variant)
+static float mfma_min_fill(int variant, int panel_rows, int64_t ldbt)
 {
+    if (panel_rows > 16 * MFMA_MAX_WAVES) return 2.0f; // the matrix-core kernel runs one wave per 16 rows of a panel
     if (variant == SPMM_VARIANT_MFMA) return 0.0f;
     if (variant == SPMM_VARIANT_NO_MFMA) return 2.0f;
-    return options().mfma_min_fill;
+    // Measured (tools/spmm_shapes.py): a chunk step of the matrix-core kernel costs ~2600 cycles of
+    // instruction issue whatever the width, so it needs 128+ dense columns (8+ MFMAs per block) to pay: block-
+    // structured rows at 60 % fill, N = 128: 0.57 ms against 0.65 ms for the LDS-tiled kernel; N = 64: 0.40 against
+    // 0.31 ms.  64-column calls therefore never take it unless SBLAS_MFMA_MIN_FILL says so.
+    const float f = options().mfma_min_fill;
+    if (f >= 0.0f) return f;
+    return ldbt >= 128 ? 0.5f : 2.0f;
 }
 
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
@@ -1331,8 +1362,8 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     const Tail t = tail_of(Bt, cols, ldbt, rows);
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant), t.hdr, t.info,
-                       t.cls, epoch);
+                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt), t.hdr,
+                       t.info, t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
 }
@@ -1362,7 +1393,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    info_rows, rowptr, colidx, /* 32-bit buffer offsets inside a wave's rows */ 1 << 24,
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
-                                   (float)info_rows / 16.0f, mfma_min_fill(variant), t.hdr, t.info, t.cls, epoch);
+                                   (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt), t.hdr, t.info, t.cls, epoch);
             dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
@@ -1379,7 +1410,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;
             }
-            if (mfma_min_fill(variant) <= 1.0f) {
+            if (mfma_min_fill(variant, info_rows, ldbt) <= 1.0f) {
                 const hipError_t e = launch_spmm_mfma(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc,
                                                       t.info, t.hdr, t.cls, info_rows, np, epoch, panel_stats_device());
                 if (e != hipSuccess) return e;

@@ -766,7 +766,8 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_e
 @pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma"])
 def test_spmm_mfma_block_structured(env, variant_env, variant, n):
     """nd24k-like rows in dense sub-blocks (60 % fill): the classifier samples the block fill and sends the panels to
-    the fp64 MFMA kernel; `mfma` forces it for every panel, `nomfma` forbids it.  Within 1e-10 relative of the oracle
+    the fp64 MFMA kernel when the call is at least 128 staged columns wide; `mfma` forces it for every panel and
+    width, `nomfma` forbids it.  Within 1e-10 relative of the oracle
     (observed: the MFMA adds a row's products in column order like the oracle's loop, zeros in between: <= 4e-16)."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
@@ -783,7 +784,8 @@ def test_spmm_mfma_block_structured(env, variant_env, variant, n):
         assert close(got, ref), (variant, n, np.abs(got - ref).max())
     census = sblas.panel_census()
     if n > 8:
-        assert (census["mfma"] > 0) == (variant != "nomfma"), census
+        # auto: the matrix cores from 128 staged columns on (a chunk step's fixed cost needs 8+ MFMAs per block to pay)
+        assert (census["mfma"] > 0) == (variant == "mfma" or (variant == "auto" and n > 64)), census
         if variant == "mfma":
             assert census["windowed"] == 0 and census["direct"] == 0, census
 

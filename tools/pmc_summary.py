@@ -1,6 +1,6 @@
 import csv, glob, collections, os, sys
 root = sys.argv[1]
-for d in sorted(glob.glob(root + '/*_set*')):
+for d in sorted(glob.glob(root + '/*set*')):
     if not os.path.isdir(d): continue
     for f in glob.glob(d+'/*/*counter_collection.csv'):
         agg = collections.defaultdict(list)
