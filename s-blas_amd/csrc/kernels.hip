@@ -896,6 +896,7 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
 // Used for the direct panels when the matrix averages fewer than 32 nonzeros per row.
 // ---------------------------------------------------------------------------------------------
 constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
+constexpr int ROWS_LONG = 512; // entries from which a row is computed by the whole workgroup
 __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
@@ -934,6 +935,18 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     if (mine) {
         p = rowptr[row];
         pend = rowptr[row + 1];
+    }
+    // Skewed matrices (the kernel is picked by the AVERAGE row length): a row of thousands of entries would walk
+    // them sixteen at a time on one DPP row while the other 63 rows of the panel wait.  Such rows are set aside here
+    // and computed by all sixteen waves together after the sweep (each wave a slice of the row, sums merged in LDS).
+    __shared__ int long_rr[ROWS_PANEL];
+    __shared__ int n_long;
+    __shared__ double lpart[16][64];
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    if (mine && pend - p > ROWS_LONG) {
+        if (k == 0) long_rr[atomicAdd(&n_long, 1)] = rr;
+        p = pend = 0;
     }
     for (int base = p; __builtin_amdgcn_ballot_w64(base < pend) != 0ull; base += 16) {
         const int idx = base + k;
@@ -979,6 +992,21 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     ctile[32 + 2 * k][rr] = a2;
     ctile[33 + 2 * k][rr] = a3;
     __syncthreads();
+    for (int i = 0; i < n_long; ++i) { // (workgroup-uniform; no trips for all but a few panels)
+        const int lrr = long_rr[i];
+        const int pa = rowptr[row0 + lrr], pb = rowptr[row0 + lrr + 1];
+        const int slice = ((pb - pa + 15) / 16 + 63) & ~63; // whole 64-entry chunks per wave
+        const int s0 = min(pa + wave * slice, pb), s1 = min(s0 + slice, pb);
+        lpart[wave][lane] = row_direct(colidx, val, Bt, (unsigned)ldbt, (unsigned)(col0 + lane), lane, s0, s1);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += lpart[w][threadIdx.x];
+            ctile[threadIdx.x][lrr] = t;
+        }
+        __syncthreads();
+    }
     const int nrows = min(ROWS_PANEL, rows - row0);
     const int ncols = min(64, n - col0);
     for (int idx = threadIdx.x; idx < 64 * ROWS_PANEL; idx += 1024) {

@@ -25,12 +25,28 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
                                                       double *__restrict__ y)
 {
     constexpr int ROWS_PER_BLOCK = 256 / LPR;
+    // a row far longer than the lane group was sized for (skewed matrices: the kernel is picked by the AVERAGE row
+    // length) would keep its LPR lanes busy for thousands of trips while the chip idles: such rows are set aside and
+    // summed by the whole block afterwards, 256 lanes striding through them
+    constexpr int LONG = 64 * LPR;
+    __shared__ int long_rows[ROWS_PER_BLOCK];
+    __shared__ int n_long;
+    __shared__ double wsum[4];
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
     const int l = threadIdx.x % LPR;
     const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / LPR;
     double s0 = 0.0, s1 = 0.0;
+    bool deferred = false;
     if (row < rows) {
         const int p1 = rowptr[row + 1];
-        int p = rowptr[row] + l;
+        int p = rowptr[row];
+        deferred = p1 - p > LONG;
+        if (deferred) {
+            if (l == 0) long_rows[atomicAdd(&n_long, 1)] = row;
+            p = p1;
+        }
+        p += l;
         // two slices per trip (four gave fewer resident waves and ran 20 % slower)
         for (; p + LPR < p1; p += 2 * LPR) {
             const int c0 = colidx[p], c1 = colidx[p + LPR];
@@ -43,9 +59,33 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
     double s = s0 + s1;
 #pragma unroll
     for (int m = LPR / 2; m > 0; m >>= 1) s += __shfl_xor(s, m, WAVE);
-    if (row < rows && l == 0) {
+    if (row < rows && l == 0 && !deferred) {
         const double r = alpha * s;
         y[row] = (beta == 0.0) ? r : fma(beta, y[row], r);
+    }
+    __syncthreads();
+    for (int i = 0; i < n_long; ++i) { // (block-uniform; zero trips for all but a few blocks)
+        const int lr = long_rows[i];
+        const int p0 = rowptr[lr], p1 = rowptr[lr + 1];
+        double t0 = 0.0, t1 = 0.0;
+        int p = p0 + (int)threadIdx.x;
+        for (; p + 256 < p1; p += 512) {
+            const int c0 = colidx[p], c1 = colidx[p + 256];
+            const double a0 = val[p], a1 = val[p + 256];
+            t0 = fma(a0, x[c0], t0);
+            t1 = fma(a1, x[c1], t1);
+        }
+        if (p < p1) t0 = fma(val[p], x[colidx[p]], t0);
+        double t = t0 + t1;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, WAVE);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double r = alpha * (wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+            y[lr] = (beta == 0.0) ? r : fma(beta, y[lr], r);
+        }
+        __syncthreads();
     }
 }
 
@@ -59,6 +99,7 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_ROWS = 256;
 constexpr int ST_CAP = 6144; // products per block (48 KiB + skew): three blocks per CU
+constexpr int ST_LONG = 96;  // rows longer than this are summed by a whole wave
 __device__ __forceinline__ int st_skew(int q) { return q + (q >> 5); } // rows of equal length: spread the LDS banks
 __global__ __launch_bounds__(ST_ROWS) void spmv_csr_stream_kernel(int rows, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
@@ -126,11 +167,28 @@ __global__ __launch_bounds__(ST_ROWS) void spmv_csr_stream_kernel(int rows, cons
                 if (p + u * ST_ROWS < total) prod[st_skew(p + u * ST_ROWS)] = a[u] * xv[u];
         }
         __syncthreads();
-        if (tid >= r0 && tid < r1) {
+        // thread r adds up row r in CSR order -- unless the row is long (skewed matrices: one thread walking a
+        // 5000-entry row holds the whole block for ~150 us): those are summed by the 64 lanes of the row's wave
+        const bool mine = tid >= r0 && tid < r1;
+        const int q0 = mine ? sp[tid] - base : 0, q1 = mine ? sp[tid + 1] - base : 0;
+        const bool longrow = q1 - q0 > ST_LONG;
+        if (mine && !longrow) {
             double sum = 0.0;
-            for (int q = sp[tid] - base, e = sp[tid + 1] - base; q < e; ++q) sum += prod[st_skew(q)];
+            for (int q = q0; q < q1; ++q) sum += prod[st_skew(q)];
             const double res = alpha * sum;
             y[row0 + tid] = (beta == 0.0) ? res : fma(beta, y[row0 + tid], res);
+        }
+        for (unsigned long long lm = __builtin_amdgcn_ballot_w64(longrow); lm; lm &= lm - 1) {
+            const int src = __builtin_ctzll(lm);                 // lane whose row this is
+            const int a = __shfl(q0, src, WAVE), b = __shfl(q1, src, WAVE);
+            double sum = 0.0;
+            for (int q = a + (tid & 63); q < b; q += WAVE) sum += prod[st_skew(q)];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) sum += __shfl_xor(sum, m, WAVE);
+            if ((tid & 63) == src) {
+                const double res = alpha * sum;
+                y[row0 + tid] = (beta == 0.0) ? res : fma(beta, y[row0 + tid], res);
+            }
         }
         if (r1 < nr) __syncthreads(); // prod is reused by the next run
         r0 = r1;

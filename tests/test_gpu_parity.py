@@ -760,6 +760,56 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_e
 
 
 # ---------------------------------------------------------------------------------------------------------
+# skewed row lengths (webbase-like: the reference authors' own SpMV profiling input, profiling.sh:16,21)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["auto", "plain", "stream", "seg4", "lds"])
+def test_spmv_power_law_rows(env, spmv_variant_env, variant):
+    """Most rows hold 1-3 entries, a few hold thousands: the kernels are picked by the AVERAGE row length, so each
+    must set its long rows aside (the lanes-per-row kernel: the whole block sums them; the stream kernel: a wave)."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    spmv_variant_env(variant)
+    M = 30011
+    rp, ci, v = synth.powerlaw(M, max_len=4000)
+    assert np.diff(rp).max() == 4000 and rp[-1] / M < 5
+    A = Dev(torch, dev, rp, ci, v, M)
+    rng = np.random.default_rng(6)
+    xh, yh = rng.standard_normal(M), rng.standard_normal(M)
+    for alpha, beta in ((1.0, 1.0), (2.5, 0.0)):
+        x, y = torch.from_numpy(xh).to(dev), torch.from_numpy(yh.copy()).to(dev)
+        sblas.spmv(M, M, A.rowptr, A.colidx, A.val, x, alpha, beta, y)
+        assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, alpha, beta)
+
+
+@pytest.mark.parametrize("variant", ["auto", "rows", "dpp"])
+@pytest.mark.parametrize("n", [8, 33, 64, 130])
+def test_spmm_power_law_rows(env, variant_env, variant, n):
+    """The same rows through the SpMM direct kernels: the four-rows-per-wave kernel hands rows of 512+ entries to the
+    whole workgroup (sixteen slices, merged in LDS); several long rows in one 64-row panel, a long row as the last
+    row of the matrix, and a panel that is all long rows."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    M = 5003
+    rp, ci, v = synth.powerlaw(M, max_len=3000)
+    lens = np.diff(rp).astype(np.int64)
+    lens[[70, 71, 100, M - 1]] = (600, 3000, 513, 1500)            # two long rows side by side, one just over the limit, the last row
+    lens[128:192] = 520                                            # a whole panel of long rows
+    rp2 = np.zeros(M + 1, np.int64)
+    np.cumsum(lens, out=rp2[1:])
+    rng = np.random.default_rng(8)
+    ci2 = np.empty(rp2[-1], np.int32)
+    for r in range(M):
+        ci2[rp2[r]:rp2[r + 1]] = np.sort(rng.choice(M, lens[r], replace=False))
+    v2 = rng.standard_normal(rp2[-1])
+    A = Dev(torch, dev, rp2.astype(np.int32), ci2, v2, M)
+    B, C0 = rng.standard_normal(M * n), rng.standard_normal(M * n)
+    got = gpu_spmm(sblas, torch, dev, A, B, M, n, 1.5, -0.5, C0, M)
+    ref = oracle.spmm(M, M, n, *A.h, B, C0.copy(), 1.5, -0.5)
+    assert close(got, ref), (variant, n, np.abs(got - ref).max())
+
+
+# ---------------------------------------------------------------------------------------------------------
 # the matrix-core (MFMA) kernel: panels whose nonzeros sit in dense 16 x 4 sub-blocks
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [1, 20, 64, 100, 128, 200])

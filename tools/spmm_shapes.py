@@ -31,6 +31,9 @@ def make(shape):
     elif kind == "qgrid":
         rp, ci, v = synth.queen_like_grid(int(parts[1]) if len(parts) > 1 else 300000)
         rows = len(rp) - 1
+    elif kind == "banded":
+        rows = int(parts[1])
+        rp, ci, v = synth.banded(rows, int(parts[2]), int(parts[3]) if len(parts) > 3 else 2000)
     elif kind == "powerlaw":
         rows = int(parts[1]) if len(parts) > 1 else 1000000
         rp, ci, v = synth.powerlaw(rows)
