@@ -30,6 +30,7 @@ enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pas
        TAIL_DIRECT_EPOCH = 2, // epoch of the classifier run that left panels to the direct kernel
        TAIL_BAND = 3,         // column span of the middle panel (band width of the matrix)
        TAIL_MFMA_EPOCH = 4,   // epoch of the classifier run that gave panels to the matrix-core kernel
+       TAIL_MFMAD_EPOCH = 5,  // ... and some of them fall back to the DIRECT kernel when B holds a non-finite value
        TAIL_HDR = 16 };
 enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3 };
 constexpr int MFMA_MAX_WAVES = 8; // 16 rows per wave: panels of up to 128 rows (taller panels never take the MFMA kernel)

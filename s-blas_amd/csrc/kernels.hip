@@ -269,7 +269,8 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         // "this call left work for the direct kernel": the launch's epoch (every writer stores the same value).  The
         // direct kernel leaves at once when the slot holds anything else -- an optimisation only: a stale or
         // accidental match merely sends it through its per-panel checks.
-        if (c == PANEL_DIRECT || c == PANEL_MFMA_D) tail[TAIL_DIRECT_EPOCH] = epoch;
+        if (c == PANEL_DIRECT) tail[TAIL_DIRECT_EPOCH] = epoch;
+        if (c == PANEL_MFMA_D) tail[TAIL_MFMAD_EPOCH] = epoch;
         if (c == PANEL_MFMA_W || c == PANEL_MFMA_D) tail[TAIL_MFMA_EPOCH] = epoch;
     }
 }
@@ -310,6 +311,48 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                        max_row_len, min_density, mfma_min_fill, tail, info, cls, epoch,
                        reinterpret_cast<unsigned *>(&tile[0][0]) + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
     }
+}
+// The stage-2 kernels run one after the other, so a matrix whose panels split between the matrix-core kernel and the
+// vector kernels pays for two half-empty launches (block-structured rows at the fill threshold, N = 128: 1.05 ms against
+// 0.63 ms for either kernel alone).  One workgroup therefore settles the matter for the whole matrix before stage 2:
+// unless at least three quarters of the non-empty panels qualified for the matrix cores, those that did go back to
+// their vector kernel.  (Launched only where the matrix-core kernel can be chosen at all: 128+ staged columns.)
+__global__ __launch_bounds__(256) void mfma_vote_kernel(int npanels, int *__restrict__ tail, const int2 *__restrict__ info,
+                                                       int *__restrict__ cls, int epoch)
+{
+    __shared__ int counts[2];
+    if (tail[TAIL_MFMA_EPOCH] != epoch) return; // no panel qualified
+    if (threadIdx.x < 2) counts[threadIdx.x] = 0;
+    __syncthreads();
+    int mine = 0, all = 0;
+    for (int p = threadIdx.x; p < npanels; p += 256) {
+        const int2 sp = info[p];
+        if (sp.x <= sp.y) {
+            ++all;
+            mine += cls[p] == PANEL_MFMA_W || cls[p] == PANEL_MFMA_D;
+        }
+    }
+    atomicAdd(&counts[0], mine);
+    atomicAdd(&counts[1], all);
+    __syncthreads();
+    if (4 * counts[0] >= 3 * counts[1]) return; // the matrix cores keep their panels
+    bool any_direct = false, any_window = false;
+    for (int p = threadIdx.x; p < npanels; p += 256) {
+        const int c = cls[p];
+        if (c == PANEL_MFMA_W) cls[p] = PANEL_WINDOW;
+        if (c == PANEL_MFMA_D) cls[p] = PANEL_DIRECT;
+        any_direct |= c == PANEL_MFMA_D;
+        any_window |= c == PANEL_MFMA_W;
+    }
+    (void)any_window;
+    if (any_direct) tail[TAIL_DIRECT_EPOCH] = epoch; // (every writer stores the same value)
+    if (threadIdx.x == 0) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel any more
+}
+// no panel of this call is left to the direct kernel (every workgroup asks this first: two scalar loads, no per-panel work)
+__device__ __forceinline__ bool nothing_direct(const int *__restrict__ tail, int epoch)
+{
+    if (tail[TAIL_DIRECT_EPOCH] == epoch) return false;
+    return !(tail[TAIL_MFMAD_EPOCH] == epoch && tail[TAIL_NONFINITE] == tail[TAIL_STAGE_EPOCH]);
 }
 // which kernel computes panel p (cls == nullptr: no classifier ran, the direct kernel computes everything)
 __device__ __forceinline__ bool b_nonfinite(const int *__restrict__ tail)
@@ -726,7 +769,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     __shared__ double ctile[TILE_COLS][WIDE_PANEL + 1];
     // every panel windowed (the bench matrix): one scalar load of one shared address and out, instead of two
     // dependent loads per workgroup (4500 workgroups of early exits took 16 us of a 340 us step)
-    if (cls != nullptr && tail[TAIL_DIRECT_EPOCH] != epoch) return;
+    if (cls != nullptr && nothing_direct(tail, epoch)) return;
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
@@ -905,7 +948,7 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
 {
     __shared__ double ctile[64][ROWS_PANEL + 1];
     __shared__ int row_mine[ROWS_PANEL];
-    if (cls != nullptr && tail[TAIL_DIRECT_EPOCH] != epoch) return; // nothing direct
+    if (cls != nullptr && nothing_direct(tail, epoch)) return;
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     const int k = lane & 15, q = lane >> 4;
@@ -1361,7 +1404,8 @@ static float mfma_min_fill(int variant, int panel_rows, int64_t ldbt)
     // Measured (tools/spmm_shapes.py): a chunk step of the matrix-core kernel costs ~2600 cycles of
     // instruction issue whatever the width, so it needs 128+ dense columns (8+ MFMAs per block) to pay: block-
     // structured rows at 60 % fill, N = 128: 0.57 ms against 0.65 ms for the LDS-tiled kernel; N = 64: 0.40 against
-    // 0.31 ms.  64-column calls therefore never take it unless SBLAS_MFMA_MIN_FILL says so.
+    // 0.31 ms; N = 256 at 35 % fill: 1.55 against 1.29 ms; grid-structured Queen-like rows (fill 0.32), N = 256: 2.33
+    // against 2.16 ms for the direct kernel.  64-column calls therefore never take it unless SBLAS_MFMA_MIN_FILL says so.
     const float f = options().mfma_min_fill;
     if (f >= 0.0f) return f;
     return ldbt >= 128 ? 0.5f : 2.0f;
@@ -1422,6 +1466,9 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
                                    (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt), t.hdr, t.info, t.cls, epoch);
+            const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
+            if (mfma_possible && variant != SPMM_VARIANT_MFMA)
+                hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(256), 0, s, np, t.hdr, t.info, t.cls, epoch);
             dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
@@ -1438,7 +1485,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;
             }
-            if (mfma_min_fill(variant, info_rows, ldbt) <= 1.0f) {
+            if (mfma_possible) {
                 const hipError_t e = launch_spmm_mfma(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc,
                                                       t.info, t.hdr, t.cls, info_rows, np, epoch, panel_stats_device());
                 if (e != hipSuccess) return e;

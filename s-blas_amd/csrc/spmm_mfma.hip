@@ -224,31 +224,29 @@ __global__ __launch_bounds__(MFMA_MAX_WAVES * 64) void spmm_mfma_kernel(
     }
     if (tid == 0 && blockIdx.y == 0) atomicAdd(&stats[3], 1ull);
 
-    // Write-back, wave by wave (no workgroup step): 64 columns at a time the wave parks its 16 x 64 results in its own
-    // image area as [column][row] and stores them with lanes along the rows -- 16 rows = 128 contiguous bytes of a
-    // column of C per quarter wave.  alpha / beta are applied here, so C is read and written exactly once.
-    const int grow0 = row0 + wave * 16;            // first matrix row of this wave
-    const int nrow = min(16, row0 + prow - grow0); // rows it really has (<= 0: none)
-    const int ncols = min(NCOLS, n - col0);
+    // park the panel as [column][row] in LDS and write it back along rows: a column of C gets the panel's rows as one
+    // contiguous run (768 bytes for 96 rows; wave-private 128-byte pieces ran 6 % slower at N = 128).  alpha / beta are
+    // applied here, so C is read and written exactly once.
+    __syncthreads(); // every wave is done with its image
+    double *ctile = reinterpret_cast<double *>(smem_raw);
+    const int pr1 = panel_rows + 1;
 #pragma unroll
-    for (int sl = 0; sl < NT / 4; ++sl) {
+    for (int t = 0; t < NT; ++t) {
+        const int cc = 32 * (t >> 1) + 2 * mi + (t & 1); // column inside the tile
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            const int t = 4 * sl + t4;
-            const int cc = 32 * (t4 >> 1) + 2 * mi + (t4 & 1); // column inside the 64-column slice
-#pragma unroll
-            for (int r = 0; r < 4; ++r) img[cc * 16 + mk + 4 * r] = acc[t][r];
+        for (int r = 0; r < 4; ++r) {
+            const int rr = wave * 16 + mk + 4 * r;
+            if (rr < panel_rows) ctile[cc * pr1 + rr] = acc[t][r];
         }
-        // (LDS accesses of one wave execute in order: no barrier between its own stores and loads)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int cj = 4 * u + (lane >> 4), r = lane & 15; // four columns per instruction
-            const int gc = 64 * sl + cj;
-            if (r < nrow && gc < ncols) {
-                double *dst = C + (int64_t)(col0 + gc) * ldc + (grow0 + r);
-                const double sres = alpha * img[cj * 16 + r];
-                *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
-            }
+    }
+    __syncthreads();
+    const int ncols = min(NCOLS, n - col0);
+    for (int idx = tid; idx < NCOLS * panel_rows; idx += blockDim.x) {
+        const int r = idx % panel_rows, cj = idx / panel_rows;
+        if (r < prow && cj < ncols) {
+            double *dst = C + (int64_t)(col0 + cj) * ldc + (row0 + r);
+            const double sres = alpha * ctile[cj * pr1 + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
         }
     }
 }
@@ -260,7 +258,9 @@ hipError_t launch_spmm_mfma(hipStream_t s, int rows, int cols, const int *rowptr
 {
     const int waves = (panel_rows + 15) / 16;
     if (waves < 1 || waves > MFMA_MAX_WAVES) return hipErrorInvalidValue;
-    size_t lds = (size_t)waves * MFMA_WAVE_LDS;
+    const size_t img_bytes = (size_t)waves * MFMA_WAVE_LDS;
+    const size_t ctile_bytes = (size_t)(ldbt == 64 ? 64 : 128) * (size_t)(panel_rows + 1) * sizeof(double);
+    size_t lds = img_bytes > ctile_bytes ? img_bytes : ctile_bytes;
     if ((size_t)options().tune[0] > lds && options().tune[0] <= 160 * 1024) lds = (size_t)options().tune[0]; // experiments: occupancy
 #define SBLAS_MFMA_LAUNCH(NTV, BV, GY)                                                                                \
     do {                                                                                                             \
