@@ -195,7 +195,8 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
         const int64_t ldbt = chunk_ldbt(cols, n, nj);
         int rc, pre_epoch = 0;
-        if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
+        if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
+            spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
             ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
             DeviceScope scope(dev);

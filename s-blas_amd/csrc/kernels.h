@@ -17,7 +17,7 @@ enum {
     SPMM_VARIANT_DIRECT_DPP = 1,  // "dpp":   every panel through the row-per-wave direct kernel
     SPMM_VARIANT_DIRECT_ROWS = 2, // "rows":  every panel through the four-rows-per-wave direct kernel
     SPMM_VARIANT_LANES = 3,       // "lanes": n <= 8 keeps the lane-group kernel whatever the row length (else AUTO)
-    SPMM_VARIANT_GRID2D = 4,      // "grid2d": every direct panel through the 2-D (row block x column block) kernel
+    SPMM_VARIANT_DIRECT_MERGE = 4, // "merge": every panel through the three-rows-per-wave direct kernel (128-column tiles)
     SPMM_VARIANT_MFMA = 5,        // "mfma":  LDS-tiled panels through the MFMA kernel whatever their block density
     SPMM_VARIANT_NO_MFMA = 6,     // "nomfma": never the MFMA kernel
 };
@@ -30,9 +30,11 @@ enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pas
        TAIL_DIRECT_EPOCH = 2, // epoch of the classifier run that left panels to the direct kernel
        TAIL_BAND = 3,         // column span of the middle panel (band width of the matrix)
        TAIL_MFMA_EPOCH = 4,   // epoch of the classifier run that gave panels to the matrix-core kernel
+       TAIL_MERGE_EPOCH = 6,  // epoch of the call whose direct panels go to the row-merging kernel (rows share column patterns)
        TAIL_MFMAD_EPOCH = 5,  // ... and some of them fall back to the DIRECT kernel when B holds a non-finite value
        TAIL_HDR = 16 };
-enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3 };
+enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3,
+       PANEL_CLASS_MASK = 0xff, PANEL_SHARED_ROWS = 0x100 /* flag: the panel's leading rows list the same columns */ };
 constexpr int MFMA_MAX_WAVES = 8; // 16 rows per wave: panels of up to 128 rows (taller panels never take the MFMA kernel)
 size_t workspace_tail_bytes(int64_t rows);
 unsigned long long *panel_stats_device();
@@ -49,6 +51,7 @@ struct Options {
     unsigned long long max_bt_bytes = 0xffffffffull; // SBLAS_SPMM_MAX_BT_BYTES (tests of the column-chunk loop)
     int direct_lds = -1;                  // SBLAS_DIRECT_LDS
     int direct_map = -1;                  // SBLAS_DIRECT_MAP: 1 interleave, 0 contiguous, -1 by span
+    int direct_merge = 1;                 // SBLAS_DIRECT_MERGE: 128-column direct panels through the row-merging kernel
     double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
     int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE

@@ -185,8 +185,8 @@ constexpr int MFMA_BITMAP_WORDS = 1024; // 32768 blocks = 131072 columns of span
 __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int npanels, int panel_rows,
                                                const int *__restrict__ rowptr, const int *__restrict__ colidx,
                                                int max_row_len, float min_density, float mfma_min_fill,
-                                               int *__restrict__ tail, int2 *__restrict__ info, int *__restrict__ cls,
-                                               int epoch, unsigned *__restrict__ bitmap)
+                                               int merge_probe, int *__restrict__ tail, int2 *__restrict__ info,
+                                               int *__restrict__ cls, int epoch, unsigned *__restrict__ bitmap)
 {
     const int lane = threadIdx.x & 63;
     if (p >= npanels) return;
@@ -259,10 +259,27 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                    (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
+    // Do neighbouring rows list the same columns (the rows of one mesh node in a multi-dof FEM matrix)?  Rows 0/1 and
+    // 1/2 of the panel are compared entry by entry; the row-merging direct kernel pays only where they do.
+    bool shared = false;
+    if (sane && !window_ok && merge_probe) {
+        const int r0 = p * panel_rows;
+        for (int k = 0; k < 2 && !shared; ++k) {
+            if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
+            const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
+            bool eq = b - a == c2 - b && b > a;
+            if (eq) {
+                bool differ = false;
+                for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
+                eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
+            }
+            shared = eq;
+        }
+    }
     if (lane == 0) {
         info[p] = last >= first ? make_int2(first, last) : make_int2(1, 0);
         const int c = mfma ? (window_ok ? PANEL_MFMA_W : PANEL_MFMA_D) : (window_ok ? PANEL_WINDOW : PANEL_DIRECT);
-        cls[p] = c;
+        cls[p] = c | (shared ? PANEL_SHARED_ROWS : 0);
         // the middle panel's column span: the direct kernels take it as the band width of the matrix when they choose
         // their panel -> XCD map (one writer)
         if (p == npanels / 2) tail[TAIL_BAND] = last >= first ? last - first + 1 : 0;
@@ -277,13 +294,13 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
 __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
                                                              const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx, int max_row_len,
-                                                             float min_density, float mfma_min_fill,
+                                                             float min_density, float mfma_min_fill, int merge_probe,
                                                              int *__restrict__ tail, int2 *__restrict__ info,
                                                              int *__restrict__ cls, int epoch)
 {
     __shared__ unsigned bitmap[4][MFMA_BITMAP_WORDS];
     classify_panel(blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx, max_row_len,
-                   min_density, mfma_min_fill, tail, info, cls, epoch, bitmap[threadIdx.x >> 6]);
+                   min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch, bitmap[threadIdx.x >> 6]);
 }
 // Stage 1 and the panel classifier in one launch (the fused C-ABI entry: both depend only on the call's inputs, and
 // the classifier's dependent loads hide behind the staging traffic): the first ceil(npanels / 4) workgroups
@@ -293,7 +310,7 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                                                             int stage_blocks, int rows, int npanels, int panel_rows,
                                                             const int *__restrict__ rowptr,
                                                             const int *__restrict__ colidx, int max_row_len,
-                                                            float min_density, float mfma_min_fill,
+                                                            float min_density, float mfma_min_fill, int merge_probe,
                                                             int *__restrict__ tail, int2 *__restrict__ info,
                                                             int *__restrict__ cls, int epoch)
 {
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                    ldbt, tail, epoch);
     } else if (blockIdx.y == 0) {
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
-                       max_row_len, min_density, mfma_min_fill, tail, info, cls, epoch,
+                       max_row_len, min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch,
                        reinterpret_cast<unsigned *>(&tile[0][0]) + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
     }
 }
@@ -318,35 +335,53 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
 // unless at least three quarters of the non-empty panels qualified for the matrix cores, those that did go back to
 // their vector kernel.  (Launched only where the matrix-core kernel can be chosen at all: 128+ staged columns.)
 __global__ __launch_bounds__(256) void mfma_vote_kernel(int npanels, int *__restrict__ tail, const int2 *__restrict__ info,
-                                                       int *__restrict__ cls, int epoch)
+                                                       int *__restrict__ cls, int epoch, int mfma_forced)
 {
-    __shared__ int counts[2];
-    if (tail[TAIL_MFMA_EPOCH] != epoch) return; // no panel qualified
-    if (threadIdx.x < 2) counts[threadIdx.x] = 0;
+    __shared__ int counts[4];
+    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
     __syncthreads();
     int mine = 0, all = 0;
     for (int p = threadIdx.x; p < npanels; p += 256) {
         const int2 sp = info[p];
+        const int c = cls[p] & PANEL_CLASS_MASK;
         if (sp.x <= sp.y) {
             ++all;
-            mine += cls[p] == PANEL_MFMA_W || cls[p] == PANEL_MFMA_D;
+            mine += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
         }
     }
     atomicAdd(&counts[0], mine);
     atomicAdd(&counts[1], all);
     __syncthreads();
-    if (4 * counts[0] >= 3 * counts[1]) return; // the matrix cores keep their panels
-    bool any_direct = false, any_window = false;
+    const bool demote = !mfma_forced && counts[0] > 0 && 4 * counts[0] < 3 * counts[1];
+    // the direct kernel's panels after the vote: do their rows share column patterns?  (half of them: the row-merging
+    // kernel takes all of the call's direct panels, otherwise the row-per-wave kernel does)
+    int direct = 0, shared = 0;
+    bool any_direct = false;
     for (int p = threadIdx.x; p < npanels; p += 256) {
-        const int c = cls[p];
-        if (c == PANEL_MFMA_W) cls[p] = PANEL_WINDOW;
-        if (c == PANEL_MFMA_D) cls[p] = PANEL_DIRECT;
-        any_direct |= c == PANEL_MFMA_D;
-        any_window |= c == PANEL_MFMA_W;
+        int c = cls[p] & PANEL_CLASS_MASK;
+        const int flag = cls[p] & PANEL_SHARED_ROWS;
+        if (demote) {
+            if (c == PANEL_MFMA_W) c = PANEL_WINDOW;
+            if (c == PANEL_MFMA_D) {
+                c = PANEL_DIRECT;
+                any_direct = true;
+            }
+            cls[p] = c | flag;
+        }
+        const int2 sp = info[p];
+        if (c == PANEL_DIRECT && sp.x <= sp.y) {
+            ++direct;
+            shared += flag != 0;
+        }
     }
-    (void)any_window;
+    atomicAdd(&counts[2], direct);
+    atomicAdd(&counts[3], shared);
     if (any_direct) tail[TAIL_DIRECT_EPOCH] = epoch; // (every writer stores the same value)
-    if (threadIdx.x == 0) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel any more
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (demote) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel any more
+        if (counts[2] > 0 && 2 * counts[3] >= counts[2]) tail[TAIL_MERGE_EPOCH] = epoch;
+    }
 }
 // no panel of this call is left to the direct kernel (every workgroup asks this first: two scalar loads, no per-panel work)
 __device__ __forceinline__ bool nothing_direct(const int *__restrict__ tail, int epoch)
@@ -361,12 +396,12 @@ __device__ __forceinline__ bool b_nonfinite(const int *__restrict__ tail)
 }
 __device__ __forceinline__ bool owns_direct(const int *__restrict__ tail, const int *__restrict__ cls, int p)
 {
-    const int c = cls[p];
+    const int c = cls[p] & PANEL_CLASS_MASK;
     return c == PANEL_DIRECT || (c == PANEL_MFMA_D && b_nonfinite(tail));
 }
 __device__ __forceinline__ bool owns_window(const int *__restrict__ tail, const int *__restrict__ cls, int p)
 {
-    const int c = cls[p];
+    const int c = cls[p] & PANEL_CLASS_MASK;
     return c == PANEL_WINDOW || (c == PANEL_MFMA_W && b_nonfinite(tail));
 }
 
@@ -770,6 +805,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     // every panel windowed (the bench matrix): one scalar load of one shared address and out, instead of two
     // dependent loads per workgroup (4500 workgroups of early exits took 16 us of a 340 us step)
     if (cls != nullptr && nothing_direct(tail, epoch)) return;
+    if (GROUPS == 1 && cls != nullptr && tail[TAIL_MERGE_EPOCH] == epoch) return; // the row-merging kernel's call
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
@@ -875,6 +911,163 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const int ncols = min(TILE_COLS, n - col0);
     for (int idx = threadIdx.x; idx < TILE_COLS * WIDE_PANEL; idx += WIDE_WAVES * 64) {
         const int r = idx % WIDE_PANEL, j = idx / WIDE_PANEL;
+        if (r < nrows && j < ncols && row_mine[r]) {
+            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
+            const double sres = alpha * ctile[j][r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stage 2, direct form for rows that share their column pattern (multi-dof FEM matrices: the rows of one mesh node --
+// Queen_4147 has three per node -- list the same columns).  The row-per-wave kernel above pulls every Bt row piece
+// through the L2 -> CU path once per ROW (grid-structured Queen-like rows at N = 256: 40 GB per call, 1.8 ms at the
+// 22 TB/s that path moves); here a wave owns MR = 3 consecutive rows and walks them chunk by chunk (64 entries):
+// where the three rows hold the same columns in a chunk, every 16-byte piece of Bt is loaded ONCE and feeds three
+// accumulator pairs (one DPP-broadcast value per row); where they differ the chunk falls back to one sweep per row.
+// Nothing is assumed: the comparison is made per chunk on the entries themselves.
+// ---------------------------------------------------------------------------------------------
+constexpr int MR = 3;
+constexpr int MERGE_PANEL = WIDE_WAVES * MR; // 48 rows per workgroup
+template <int NR>
+__device__ __forceinline__ void merged_sweeps(int cj, const double (&vj)[NR], int cnt, double (&acc)[NR][2], int sub,
+                                              unsigned ldb8, unsigned lb, unsigned zero_off,
+                                              const char *__restrict__ bt_bytes)
+{
+    for (int g0 = 0; g0 < cnt; g0 += 16) {
+        const int e = g0 + sub; // slot `sub` of every DPP row takes chunk entry e
+        const int src = e << 2;
+        const bool on = e < cnt;
+        const int gc = __builtin_amdgcn_ds_bpermute(src, cj);
+        const unsigned co = on ? (unsigned)gc * ldb8 : zero_off;
+        double gvr[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(vj[r]));
+            const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(vj[r]));
+            gvr[r] = on ? __hiloint2double(hi, lo) : 0.0;
+        }
+        const int ng = min(16, cnt - g0);
+        unsigned o0, o1, o2, o3, o4, o5, o6, o7, o8, o9, o10, o11, o12, o13, o14, o15;
+        double2 b0, b1, b2, b3, b4, b5, b6, b7, b8, b9, b10, b11, b12, b13, b14, b15;
+#define SBLAS_LD(O) (*reinterpret_cast<const double2 *>(bt_bytes + (O)))
+        // every piece of the sweep in flight before the first FMA
+        SBLAS_DPP_OFF4(0, 1, 2, 3, o0, o1, o2, o3);
+        b0 = SBLAS_LD(o0); b1 = SBLAS_LD(o1); b2 = SBLAS_LD(o2); b3 = SBLAS_LD(o3);
+        if (ng > 4) {
+            SBLAS_DPP_OFF4(4, 5, 6, 7, o4, o5, o6, o7);
+            b4 = SBLAS_LD(o4); b5 = SBLAS_LD(o5); b6 = SBLAS_LD(o6); b7 = SBLAS_LD(o7);
+        }
+        if (ng > 8) {
+            SBLAS_DPP_OFF4(8, 9, 10, 11, o8, o9, o10, o11);
+            b8 = SBLAS_LD(o8); b9 = SBLAS_LD(o9); b10 = SBLAS_LD(o10); b11 = SBLAS_LD(o11);
+        }
+        if (ng > 12) {
+            SBLAS_DPP_OFF4(12, 13, 14, 15, o12, o13, o14, o15);
+            b12 = SBLAS_LD(o12); b13 = SBLAS_LD(o13); b14 = SBLAS_LD(o14); b15 = SBLAS_LD(o15);
+        }
+#undef SBLAS_LD
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double gv = gvr[r];
+            double &acc0 = acc[r][0], &acc1 = acc[r][1];
+            SBLAS_DPP_FMA4x2(0, 1, 2, 3, b0, b1, b2, b3);
+            if (ng > 4) { SBLAS_DPP_FMA4x2(4, 5, 6, 7, b4, b5, b6, b7); }
+            if (ng > 8) { SBLAS_DPP_FMA4x2(8, 9, 10, 11, b8, b9, b10, b11); }
+            if (ng > 12) { SBLAS_DPP_FMA4x2(12, 13, 14, 15, b12, b13, b14, b15); }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_merge_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
+    int info_panel_rows, int interleave, int epoch)
+{
+    constexpr int TILE_COLS = 128;
+    extern __shared__ __attribute__((aligned(16))) double merge_smem[];
+    double(*ctile)[MERGE_PANEL + 1] = reinterpret_cast<double(*)[MERGE_PANEL + 1]>(merge_smem); // [TILE_COLS][MERGE_PANEL + 1]
+    __shared__ int row_mine[MERGE_PANEL];
+    if (cls != nullptr && (nothing_direct(tail, epoch) || tail[TAIL_MERGE_EPOCH] != epoch)) return; // the row-per-wave kernel's call
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_uniform(threadIdx.x >> 6);
+    if (interleave < 0) { // wide bands: neighbouring panels on different XCDs (see spmm_direct_dpp_kernel)
+        interleave = 0;
+        if (cls != nullptr) interleave = (long long)tail[TAIL_BAND] * (TILE_COLS * 8) > (16ll << 20);
+    }
+    const int row0 = (interleave ? (int)blockIdx.x : xcd_contiguous_panel(blockIdx.x, npanels)) * MERGE_PANEL;
+    const int col0 = blockIdx.y * TILE_COLS;
+    const int sub = lane & 15;
+    const unsigned ldb8 = (unsigned)ldbt * 8u;
+    const unsigned lb = (unsigned)(col0 * 8) + (unsigned)lane * 16u; // this lane's 2 columns
+    const unsigned zero_off = (unsigned)cols * ldb8;
+    const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
+
+    int p0[MR], len[MR];
+    bool mine[MR];
+    bool all_mine = true;
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        const int row = row0 + wave * MR + r;
+        mine[r] = row < rows;
+        if (cls && mine[r]) {
+            mine[r] = owns_direct(tail, cls, row / info_panel_rows);
+            if (mine[r] && lane == 0 && blockIdx.y == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
+        }
+        p0[r] = len[r] = 0;
+        if (mine[r]) {
+            p0[r] = wave_uniform(rowptr[row]);
+            len[r] = wave_uniform(rowptr[row + 1]) - p0[r];
+        }
+        all_mine = all_mine && mine[r];
+    }
+    double acc[MR][2];
+#pragma unroll
+    for (int r = 0; r < MR; ++r) acc[r][0] = acc[r][1] = 0.0;
+    const int maxlen = max(len[0], max(len[1], len[2]));
+    for (int q = 0; q < maxlen; q += WAVE) {
+        int cj[MR], cnt[MR];
+        double vj[MR];
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            cnt[r] = min(WAVE, max(len[r] - q, 0));
+            cj[r] = 0;
+            vj[r] = 0.0;
+            if (lane < cnt[r]) {
+                cj[r] = colidx[p0[r] + q + lane];
+                vj[r] = val[p0[r] + q + lane];
+            }
+        }
+        const bool same = all_mine && cnt[1] == cnt[0] && cnt[2] == cnt[0] &&
+                          __builtin_amdgcn_ballot_w64(lane < cnt[0] && (cj[1] != cj[0] || cj[2] != cj[0])) == 0ull;
+        if (same) {
+            merged_sweeps<MR>(cj[0], vj, cnt[0], acc, sub, ldb8, lb, zero_off, bt_bytes);
+        } else {
+#pragma unroll
+            for (int r = 0; r < MR; ++r) {
+                if (cnt[r] > 0) { // (wave-uniform)
+                    const double v1[1] = {vj[r]};
+                    double a1[1][2] = {{acc[r][0], acc[r][1]}};
+                    merged_sweeps<1>(cj[r], v1, cnt[r], a1, sub, ldb8, lb, zero_off, bt_bytes);
+                    acc[r][0] = a1[0][0];
+                    acc[r][1] = a1[0][1];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < MR; ++r) {
+        if (lane == 0) row_mine[wave * MR + r] = mine[r] ? 1 : 0;
+        ctile[2 * lane][wave * MR + r] = acc[r][0];
+        ctile[2 * lane + 1][wave * MR + r] = acc[r][1];
+    }
+    __syncthreads();
+    const int nrows = min(MERGE_PANEL, rows - row0);
+    const int ncols = min(TILE_COLS, n - col0);
+    for (int idx = threadIdx.x; idx < TILE_COLS * MERGE_PANEL; idx += WIDE_WAVES * 64) {
+        const int r = idx % MERGE_PANEL, j = idx / MERGE_PANEL;
         if (r < nrows && j < ncols && row_mine[r]) {
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
             const double sres = alpha * ctile[j][r];
@@ -1280,7 +1473,7 @@ static void options_parse(Options &o)
         if (!strcmp(e, "dpp")) o.spmm_variant = SPMM_VARIANT_DIRECT_DPP;
         else if (!strcmp(e, "rows")) o.spmm_variant = SPMM_VARIANT_DIRECT_ROWS;
         else if (!strcmp(e, "lanes")) o.spmm_variant = SPMM_VARIANT_LANES;
-        else if (!strcmp(e, "grid2d")) o.spmm_variant = SPMM_VARIANT_GRID2D;
+        else if (!strcmp(e, "merge")) o.spmm_variant = SPMM_VARIANT_DIRECT_MERGE;
         else if (!strcmp(e, "mfma")) o.spmm_variant = SPMM_VARIANT_MFMA;
         else if (!strcmp(e, "nomfma")) o.spmm_variant = SPMM_VARIANT_NO_MFMA;
     }
@@ -1293,6 +1486,7 @@ static void options_parse(Options &o)
         if (v >= 4096 && v < 0xffffffffull) o.max_bt_bytes = v;
     }
     if ((e = getenv("SBLAS_DIRECT_LDS")) && *e) o.direct_lds = atoi(e);
+    if ((e = getenv("SBLAS_DIRECT_MERGE")) && *e) o.direct_merge = atoi(e);
     if ((e = getenv("SBLAS_DIRECT_MAP")) && *e) o.direct_map = !strcmp(e, "interleave") ? 1 : !strcmp(e, "contiguous") ? 0 : -1;
     if ((e = getenv("SBLAS_ROWS8_MIN_AVG")) && *e) o.rows8_min_avg = atof(e);
     if ((e = getenv("SBLAS_SPMM_PANEL_ROWS")) && *e) { /* "<rows>" or "<rows>,<groups>" */
@@ -1434,8 +1628,8 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     const Tail t = tail_of(Bt, cols, ldbt, rows);
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt), t.hdr,
-                       t.info, t.cls, epoch);
+                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt),
+                       (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
 }
@@ -1451,7 +1645,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         const int *cls = nullptr;
         int info_rows = 1;
         // pre_epoch != 0: launch_stage_classify has classified the panels already
-        const bool classified = variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS;
+        const bool classified = variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
+                                variant != SPMM_VARIANT_DIRECT_MERGE;
         const bool preclassified = pre_epoch != 0 && classified;
         const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         if (classified) {
@@ -1465,10 +1660,13 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    info_rows, rowptr, colidx, /* 32-bit buffer offsets inside a wave's rows */ 1 << 24,
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
-                                   (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt), t.hdr, t.info, t.cls, epoch);
+                                   (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt),
+                                   (ldbt >= 128 && opt.direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
-            if (mfma_possible && variant != SPMM_VARIANT_MFMA)
-                hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(256), 0, s, np, t.hdr, t.info, t.cls, epoch);
+            // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)
+            if (ldbt >= 128)
+                hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(256), 0, s, np, t.hdr, t.info, t.cls, epoch,
+                                   variant == SPMM_VARIANT_MFMA ? 1 : 0);
             dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
@@ -1514,10 +1712,25 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls,
                                info_rows, interleave, epoch);
         } else {
-            if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<1>, pad);
-            hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, dim3((unsigned)wide_panels, (unsigned)(ldbt / 128)),
-                               dim3(WIDE_WAVES * 64), pad, s, rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n,
-                               alpha, beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
+            // 128-column tiles.  Classified calls launch both direct kernels: the classifier's vote (device side) says
+            // whether the rows share column patterns, and the kernel whose call it is not leaves on one scalar load.
+            const bool merge = variant == SPMM_VARIANT_DIRECT_MERGE || (cls != nullptr && opt.direct_merge);
+            const bool plain = variant != SPMM_VARIANT_DIRECT_MERGE;
+            if (merge) {
+                // rows that share their column pattern (multi-dof FEM): three rows per wave, shared Bt loads
+                const int mp = (rows + MERGE_PANEL - 1) / MERGE_PANEL;
+                const size_t lds = std::max((size_t)128 * (MERGE_PANEL + 1) * sizeof(double), pad);
+                raise_dynamic_lds((const void *)spmm_direct_merge_kernel, lds);
+                hipLaunchKernelGGL(spmm_direct_merge_kernel, dim3((unsigned)mp, (unsigned)(ldbt / 128)),
+                                   dim3(WIDE_WAVES * 64), lds, s, rows, cols, mp, rowptr, colidx, val, Bt, ldbt, n, alpha,
+                                   beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
+            }
+            if (plain) {
+                if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<1>, pad);
+                hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, dim3((unsigned)wide_panels, (unsigned)(ldbt / 128)),
+                                   dim3(WIDE_WAVES * 64), pad, s, rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n,
+                                   alpha, beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
+            }
         }
     } else {
         const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);

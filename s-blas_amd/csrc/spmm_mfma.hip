@@ -63,7 +63,7 @@ __global__ __launch_bounds__(MFMA_MAX_WAVES * 64) void spmm_mfma_kernel(
     if (tail[TAIL_MFMA_EPOCH] != epoch) return;
     const int panel = mfma_xcd_panel(blockIdx.x, gridDim.x);
     // this kernel owns the panel when the classifier marked it and stage 1 saw only finite values in B
-    const int pc = cls[panel];
+    const int pc = cls[panel] & PANEL_CLASS_MASK;
     if ((pc != PANEL_MFMA_W && pc != PANEL_MFMA_D) || tail[TAIL_NONFINITE] == tail[TAIL_STAGE_EPOCH]) return;
     (void)info;
 

@@ -12,7 +12,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 # SBLAS_SPMM_VARIANT values (kernels.h): every stage-2 selection the library can be pinned to
-SPMM_VARIANTS = ["auto", "dpp", "rows", "lanes", "grid2d", "mfma", "nomfma"]
+SPMM_VARIANTS = ["auto", "dpp", "rows", "lanes", "merge", "mfma", "nomfma"]
 
 RTOL = 1e-10          # north_star: "fp64 within 1e-10 rel"
 ATOL = 1e-12          # floor for results near zero (inputs are O(1), sums O(1e2))
@@ -684,7 +684,7 @@ def test_spmm_windowed_fallback_on_unsorted_rows(env, variant_env, variant, dama
     assert close(got, ref), (variant, damage, np.abs(got - ref).max())
 
 
-@pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma", "grid2d"])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "nomfma", "merge"])
 def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     """Dense-band panels next to sparse wide-span panels (direct path chosen per panel), empty rows, rows longer
     than several chunks, and a method-2 style row block (re-based row pointers, C offset, ldc > rows)."""
