@@ -14,7 +14,7 @@ for per in [int(a) for a in sys.argv[1].split(",")]:
     ws = torch.empty(S.spmm_workspace_bytes(rows, rows, len(ci), n) // 8, dtype=torch.float64, device=dev)
     out = []
     for thr in ("100000", "1"):
-        os.environ["SBLAS_ROWS8_MIN_AVG"] = thr
+        os.environ["SBLAS_ROWS8_MIN_AVG"] = thr; S.reload_env()
         for _ in range(3): S.spmm(rows, rows, rowptr, colidx, val, B, rows, n, 1.0, 0.0, C, rows, ws)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

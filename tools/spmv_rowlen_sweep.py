@@ -14,7 +14,7 @@ for per in [int(a) for a in sys.argv[1].split(",")]:
     alg = len(ci) * 12 + rows * 28
     out = []
     for var in sys.argv[2].split(","):
-        os.environ["SBLAS_SPMV_VARIANT"] = var
+        os.environ["SBLAS_SPMV_VARIANT"] = var; S.reload_env()
         for _ in range(3): S.spmv(rows, rows, rowptr, colidx, val, x, 1.0, 0.0, y)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

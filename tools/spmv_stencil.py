@@ -14,7 +14,7 @@ for per, hb in ((5, 4), (7, 6), (13, 12), (27, 40)):
     alg = len(ci) * 12 + rows * 28
     out = []
     for var in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["auto"]):
-        os.environ["SBLAS_SPMV_VARIANT"] = var
+        os.environ["SBLAS_SPMV_VARIANT"] = var; S.reload_env()
         for _ in range(3): S.spmv(rows, rows, rowptr, colidx, val, x, 1.0, 0.0, y)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
