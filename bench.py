@@ -450,6 +450,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo + --fold-ranks rehearses the N>1 code path on one GPU")
     ap.add_argument("--fold-ranks", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--product-merge-child", type=str, default=None,
+                    help="internal: run the product_merge sections on the given comma-separated devices and print their JSON")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="seconds the product_merge child process may take")
     ap.add_argument("--op", choices=["spmm", "spmv"], default="spmm",
                     help="spmm (the headline metric) or spmv (same matrix, x = y0 = 1; secondary measurement)")
     args = ap.parse_args()
@@ -457,6 +460,18 @@ def main():
     import torch
     import sblas_amd as S
     S.lib()   # fail loudly if the HIP library is missing
+
+    if args.product_merge_child is not None:
+        # child process of rank 0: the product's own merge over the job's GPUs, isolated so that a stuck collective on
+        # hardware this code has never run on (comm.hip's distinct-device branches) cannot cost the headline line
+        devs = [int(x) for x in args.product_merge_child.split(",")]
+        torch.cuda.set_device(devs[0])
+        name, rows, cols, nnz, rp, ci, v = load_workload(args)
+        multi = len(set(devs)) > 1
+        res = product_merge_sections(args, torch, S, devs if multi else devs[:1] * 4, devs if multi else devs[:1] * 8,
+                                     rows, cols, rp, ci, v)
+        print("PRODUCT_MERGE_JSON " + json.dumps(res), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -760,12 +775,26 @@ def main():
                     for key, sec in out["secondary"].items():
                         if not sec["oracle_check"]:
                             failures.append("secondary (%s) does not match the oracle: max diff %g" % (key, sec["oracle_max_abs_diff"]))
-                # the product's own merge: all GPUs of the job from this one process; one GPU: folded ranks (g = 4 / 8)
+                # the product's own merge: all GPUs of the job driven from ONE process (a child of rank 0, so that a
+                # hang on untried hardware paths costs a timeout, not the line); one GPU: folded ranks (g = 4 / 8)
                 ndev = 1 if args.fold_ranks else min(world, torch.cuda.device_count())
-                devs4 = list(range(ndev)) if ndev > 1 else [local_rank] * 4
-                devs8 = list(range(ndev)) if ndev > 1 else [local_rank] * 8
-                out["product_merge"] = product_merge_sections(args, torch, S, devs4, devs8, rows, cols, rp, ci, v)
-                for key, sec in out["product_merge"].items():
+                devs = list(range(ndev)) if ndev > 1 else [local_rank]
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--product-merge-child", ",".join(str(d_) for d_ in devs),
+                       "--scale", str(args.scale), "--merge-steps", str(args.merge_steps), "--queen-rows", str(args.queen_rows)]
+                if args.matrix:
+                    cmd += ["--matrix", args.matrix]
+                env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+                try:
+                    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=args.extras_timeout, env=env)
+                    lines = [l for l in cp.stdout.splitlines() if l.startswith("PRODUCT_MERGE_JSON ")]
+                    if cp.returncode == 0 and lines:
+                        out["product_merge"] = json.loads(lines[-1][len("PRODUCT_MERGE_JSON "):])
+                    else:
+                        out["product_merge_error"] = "child rc=%d: %s" % (cp.returncode, (cp.stderr or cp.stdout)[-400:])
+                except subprocess.TimeoutExpired:
+                    out["product_merge_error"] = "child process exceeded %.0f s and was stopped" % args.extras_timeout
+                for key, sec in out.get("product_merge", {}).items():
                     if not sec["oracle_check"]:
                         failures.append("product_merge %s does not match the oracle: max diff %g" % (key, sec["oracle_max_abs_diff"]))
             except Exception as ex:                  # extras never cost the headline line

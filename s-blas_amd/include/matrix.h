@@ -40,6 +40,38 @@ template <typename T> T *to_device_async(unsigned gpu, const T *host, size_t cou
     return d;
 }
 
+// `replicate` placement of one host array on g GPUs (reference matrix.h:331-355, :546-553: g blocking H2D copies, one
+// GPU after the other).  Default: g asynchronous H2D copies, one per GPU stream, all in flight at once -- every GPU of
+// an MI355X node has its own PCIe 5 x16 link.  SBLAS_REPLICATE=p2p: ONE H2D copy to GPU 0, then GPU 0 -> GPU i over
+// xGMI (hipMemcpyPeerAsync on stream i behind an event on stream 0; the mesh gives every pair its own link), for
+// hosts where the PCIe side (one switch, one memory channel) is the limit.  Unmeasured: the pool has one-GPU boxes
+// only, where it degenerates to device-to-device copies.
+template <typename T> void replicate_async(unsigned g, const T *host, size_t count, T **out)
+{
+    static const bool p2p = [] {
+        const char *e = getenv("SBLAS_REPLICATE");
+        return e && !strcmp(e, "p2p");
+    }();
+    if (!p2p || g < 2 || count == 0) {
+        for (unsigned i = 0; i < g; ++i) out[i] = to_device_async(i, host, count);
+        return;
+    }
+    out[0] = to_device_async(0, host, count);
+    hipEvent_t landed;
+    CUDA_SAFE_CALL(cudaSetDevice(0));
+    sblas_rt::must(hipEventCreateWithFlags(&landed, hipEventDisableTiming), "hipEventCreate");
+    sblas_rt::must(hipEventRecord(landed, sblas_rt::stream(0)), "hipEventRecord");
+    for (unsigned i = 1; i < g; ++i) {
+        CUDA_SAFE_CALL(cudaSetDevice((int)i));
+        SAFE_ALOC_GPU(out[i], count * sizeof(T));
+        sblas_rt::must(hipStreamWaitEvent(sblas_rt::stream(i), landed, 0), "hipStreamWaitEvent");
+        sblas_rt::must(hipMemcpyPeerAsync(out[i], sblas_rt::physical_device(i), out[0], sblas_rt::physical_device(0),
+                                          count * sizeof(T), sblas_rt::stream(i)),
+                       "hipMemcpyPeerAsync");
+    }
+    sblas_rt::must(hipEventDestroy(landed), "hipEventDestroy"); // (released once the recorded work has completed)
+}
+
 // exact block partition of `total` leading-dimension units over g GPUs (DenseMatrix segment policy)
 inline void dense_block(size_t total, unsigned g, unsigned i, size_t &offset, size_t &dim)
 {
@@ -293,11 +325,9 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
         SAFE_ALOC_HOST(csrVal_gpu, n_gpu * sizeof(DataType *));
         for (unsigned i = 0; i < n_gpu; ++i) csrRowPtr_gpu[i] = NULL, csrColIdx_gpu[i] = NULL, csrVal_gpu[i] = NULL;
         if (policy == replicate) {
-            for (unsigned i = 0; i < n_gpu; ++i) {
-                csrRowPtr_gpu[i] = sblas_detail::to_device_async(i, csrRowPtr, (size_t)height + 1);
-                csrColIdx_gpu[i] = sblas_detail::to_device_async(i, csrColIdx, (size_t)nnz);
-                csrVal_gpu[i] = sblas_detail::to_device_async(i, csrVal, (size_t)nnz);
-            }
+            sblas_detail::replicate_async(n_gpu, csrRowPtr, (size_t)height + 1, csrRowPtr_gpu);
+            sblas_detail::replicate_async(n_gpu, csrColIdx, (size_t)nnz, csrColIdx_gpu);
+            sblas_detail::replicate_async(n_gpu, csrVal, (size_t)nnz, csrVal_gpu);
         } else if (policy == segment) {
             static_assert(sizeof(IdxType) == 4, "segmenting needs 32-bit row pointers");
             SAFE_ALOC_HOST(nnz_gpu, n_gpu * sizeof(IdxType));
@@ -443,7 +473,7 @@ template <typename IdxType, typename DataType> class DenseMatrix {
         assert(policy != none);
         SAFE_ALOC_HOST(val_gpu, n_gpu * sizeof(DataType *));
         if (policy == replicate) {
-            for (unsigned i = 0; i < n_gpu; ++i) val_gpu[i] = sblas_detail::to_device_async(i, val, get_mtx_num());
+            sblas_detail::replicate_async(n_gpu, val, get_mtx_num(), val_gpu);
         } else {
             SAFE_ALOC_HOST(dim_gpu, n_gpu * sizeof(IdxType));
             const size_t first = (order == row_major) ? (size_t)height : (size_t)width;
@@ -583,7 +613,7 @@ template <typename IdxType, typename DataType> class DenseVector {
         assert(policy != none);
         assert(policy != segment); // vectors are never partitioned
         SAFE_ALOC_HOST(val_gpu, n_gpu * sizeof(DataType *));
-        for (unsigned i = 0; i < n_gpu; ++i) val_gpu[i] = sblas_detail::to_device_async(i, val, get_vec_length());
+        sblas_detail::replicate_async(n_gpu, val, get_vec_length(), val_gpu);
         sblas_rt::sync_all(n_gpu);
     }
     void sync2cpu(unsigned i_gpu) // every GPU holds the same result; take any

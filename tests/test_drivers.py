@@ -13,8 +13,9 @@ BIN = os.path.join(ROOT, "s-blas_amd", "bin")
 REF = "/root/reference"
 
 
-def run(exe, *args, cwd=None):
-    p = subprocess.run([os.path.join(BIN, exe)] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, timeout=600)
+def run(exe, *args, cwd=None, env=None):
+    p = subprocess.run([os.path.join(BIN, exe)] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd, timeout=600,
+                       env=None if env is None else dict(os.environ, **env))
     return p.returncode, p.stdout + p.stderr
 
 
@@ -64,6 +65,16 @@ def test_drivers_on_gpu(sblas, cuda, gpus):
                  ("spmm_test", 1, ASH85, 64, 1.0, 1.0, gpus), ("spmm_test", 2, ASH85, 64, 1.0, 1.0, gpus),
                  ("spmm_test", 2, ASH85, 256, 3.0, 4.0, gpus)):
         rc, out = run(*args)
+        assert rc == 0 and "Validation = True" in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SBLAS_REPLICATE": "p2p"}, {"SBLAS_MERGE": "allreduce"}])
+def test_drivers_placement_and_merge_switches(sblas, cuda, env):
+    """SBLAS_REPLICATE=p2p: `replicate` placement as one H2D copy + peer copies (matrix.h:331-355's replacement, N3);
+    SBLAS_MERGE=allreduce: the reference's merge pattern.  Four logical GPUs (folded onto the devices present)."""
+    for args in (("spmm_test", 1, ASH85, 64, 1.0, 1.0, 4), ("spmm_test", 2, ASH85, 64, 3.0, 4.0, 4), ("spmv_test", ASH85, 3.0, 4.0, 4)):
+        rc, out = run(*args, env=env)
         assert rc == 0 and "Validation = True" in out, out[-1500:]
 
 
