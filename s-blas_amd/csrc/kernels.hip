@@ -334,14 +334,14 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
 // 0.63 ms for either kernel alone).  One workgroup therefore settles the matter for the whole matrix before stage 2:
 // unless at least three quarters of the non-empty panels qualified for the matrix cores, those that did go back to
 // their vector kernel.  (Launched only where the matrix-core kernel can be chosen at all: 128+ staged columns.)
-__global__ __launch_bounds__(256) void mfma_vote_kernel(int npanels, int *__restrict__ tail, const int2 *__restrict__ info,
+__global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__restrict__ tail, const int2 *__restrict__ info,
                                                        int *__restrict__ cls, int epoch, int mfma_forced)
 {
     __shared__ int counts[4];
     if (threadIdx.x < 4) counts[threadIdx.x] = 0;
     __syncthreads();
     int mine = 0, all = 0;
-    for (int p = threadIdx.x; p < npanels; p += 256) {
+    for (int p = threadIdx.x; p < npanels; p += 1024) {
         const int2 sp = info[p];
         const int c = cls[p] & PANEL_CLASS_MASK;
         if (sp.x <= sp.y) {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void mfma_vote_kernel(int npanels, int *__rest
     // kernel takes all of the call's direct panels, otherwise the row-per-wave kernel does)
     int direct = 0, shared = 0;
     bool any_direct = false;
-    for (int p = threadIdx.x; p < npanels; p += 256) {
+    for (int p = threadIdx.x; p < npanels; p += 1024) {
         int c = cls[p] & PANEL_CLASS_MASK;
         const int flag = cls[p] & PANEL_SHARED_ROWS;
         if (demote) {
@@ -929,7 +929,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
 // Nothing is assumed: the comparison is made per chunk on the entries themselves.
 // ---------------------------------------------------------------------------------------------
 constexpr int MR = 3;
-constexpr int MERGE_PANEL = WIDE_WAVES * MR; // 48 rows per workgroup
+constexpr int MERGE_WAVES = 8;               // 24 rows per workgroup, two workgroups per CU
+constexpr int MERGE_PANEL = MERGE_WAVES * MR;
 template <int NR>
 __device__ __forceinline__ void merged_sweeps(int cj, const double (&vj)[NR], int cnt, double (&acc)[NR][2], int sub,
                                               unsigned ldb8, unsigned lb, unsigned zero_off,
@@ -980,7 +981,7 @@ __device__ __forceinline__ void merged_sweeps(int cj, const double (&vj)[NR], in
     }
 }
 
-__global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_merge_kernel(
+__global__ __launch_bounds__(MERGE_WAVES * 64) void spmm_direct_merge_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_merge_kernel(
     __syncthreads();
     const int nrows = min(MERGE_PANEL, rows - row0);
     const int ncols = min(TILE_COLS, n - col0);
-    for (int idx = threadIdx.x; idx < TILE_COLS * MERGE_PANEL; idx += WIDE_WAVES * 64) {
+    for (int idx = threadIdx.x; idx < TILE_COLS * MERGE_PANEL; idx += MERGE_WAVES * 64) {
         const int r = idx % MERGE_PANEL, j = idx / MERGE_PANEL;
         if (r < nrows && j < ncols && row_mine[r]) {
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
@@ -1665,7 +1666,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
             // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)
             if (ldbt >= 128)
-                hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(256), 0, s, np, t.hdr, t.info, t.cls, epoch,
+                hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(1024), 0, s, np, t.hdr, t.info, t.cls, epoch,
                                    variant == SPMM_VARIANT_MFMA ? 1 : 0);
             dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
             KernelEvents *kev = kernel_events_slot();
@@ -1719,10 +1720,10 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             if (merge) {
                 // rows that share their column pattern (multi-dof FEM): three rows per wave, shared Bt loads
                 const int mp = (rows + MERGE_PANEL - 1) / MERGE_PANEL;
-                const size_t lds = std::max((size_t)128 * (MERGE_PANEL + 1) * sizeof(double), pad);
+                const size_t lds = (size_t)128 * (MERGE_PANEL + 1) * sizeof(double);
                 raise_dynamic_lds((const void *)spmm_direct_merge_kernel, lds);
                 hipLaunchKernelGGL(spmm_direct_merge_kernel, dim3((unsigned)mp, (unsigned)(ldbt / 128)),
-                                   dim3(WIDE_WAVES * 64), lds, s, rows, cols, mp, rowptr, colidx, val, Bt, ldbt, n, alpha,
+                                   dim3(MERGE_WAVES * 64), lds, s, rows, cols, mp, rowptr, colidx, val, Bt, ldbt, n, alpha,
                                    beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
             }
             if (plain) {
