@@ -626,6 +626,44 @@ def test_full_size_properties(env):
     assert close(got[:, sample], ref.reshape(N, rows)[:, sample])
 
 
+def test_config5_full_size_on_one_gpu(env):
+    """BASELINE config 5's size on one GPU: 4 147 110 rows (Queen_4147's), grid-structured Queen-like rows (~275 M
+    nonzeros), N = 256.  Bt for 256 columns would be 8.5 GB, beyond the kernels' 32-bit byte offsets, so the call walks
+    two 128-column chunks over a 4.25 GB staging copy (row offsets up to 99 % of 2^32) -- with the row-merging direct
+    kernel.  Properties: B = ones gives the row sums in every column; oracle windows at both ends and in the middle
+    on a random B with alpha, beta != trivial."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rp, ci, v = synth.queen_like_grid(4147110)
+    rows = len(rp) - 1
+    N = 256
+    assert rows > 4_000_000 and (rows + 1) * 256 * 8 > 2 ** 32
+    A = Dev(torch, dev, rp, ci, v, rows)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), N) // 8, dtype=torch.float64, device=dev)
+    assert ws.numel() * 8 < 5 * 2 ** 30                            # one 128-column chunk, not 256 columns
+    C = torch.zeros(rows * N, dtype=torch.float64, device=dev)
+    B = torch.ones(rows * N, dtype=torch.float64, device=dev)
+    sblas.panel_census()
+    sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, N, 1.0, 0.0, C, rows, ws)
+    census = sblas.panel_census()
+    assert census["direct"] > 0 and census["windowed"] == 0, census
+    lens = torch.from_numpy(np.diff(rp).astype(np.int64)).to(dev)
+    rowsum = torch.segment_reduce(A.val, "sum", lengths=lens)
+    for j in (0, 127, 128, 255):                                   # both chunks
+        assert torch.allclose(C.view(N, rows)[j], rowsum, rtol=1e-10, atol=1e-11), j
+    del lens, rowsum
+    g = torch.Generator(device=dev).manual_seed(211)
+    B.uniform_(0.0, 1.0, generator=g)
+    C.fill_(1.0)
+    sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, N, 3.0, 4.0, C, rows, ws)
+    Bh = B.cpu().numpy()
+    ref = np.ones(rows * N)
+    got = C.view(N, rows)
+    for r0 in (0, rows // 2, rows - 64):
+        oracle.spmm_rows(r0, r0 + 64, rows, rows, N, rp, ci, v, Bh, ref, 3.0, 4.0)
+        assert close(got[:, r0:r0 + 64].cpu().numpy(), ref.reshape(N, rows)[:, r0:r0 + 64]), r0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the windowed (row panel x LDS B tile) kernel and its per-panel fallback
 # ---------------------------------------------------------------------------------------------------------
