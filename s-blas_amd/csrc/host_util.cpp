@@ -6,9 +6,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <sys/stat.h>
+#include <atomic>
+#include <thread>
+#include <chrono>
 #include <vector>
 #include "../../include/sblas_hip.h"
 
@@ -140,17 +144,131 @@ inline bool parse_real(const char *&p, const char *end, double &out)
     return true;
 }
 
+// one entry = tpe whitespace-separated tokens: "i j [re [im]]"
+inline bool parse_entry(const char *&p, const char *end, Field field, long M, long N, bool mirrored, int32_t &ri,
+                        int32_t &ci, double &v)
+{
+    long i = 0, j = 0;
+    double re = 1.0;
+    if (!parse_int(p, end, i) || !parse_int(p, end, j)) return false;
+    if (field == F_REAL) {
+        if (!parse_real(p, end, re)) return false;
+    } else if (field == F_COMPLEX) {
+        double im;
+        if (!parse_real(p, end, re) || !parse_real(p, end, im)) return false; // imaginary part dropped
+    } else if (field == F_INTEGER) {
+        long iv;
+        if (!parse_int(p, end, iv)) return false;
+        re = (double)(int)iv;
+    }
+    if (i < 1 || i > M || j < 1 || j > N) return false; // the reference would write out of bounds
+    if (mirrored && i != j && (j > M || i > N)) return false;
+    ri = (int32_t)(i - 1);
+    ci = (int32_t)(j - 1);
+    v = re;
+    return true;
+}
+
+// The entry list of a large file, tokenised by several threads (the first, uncached parse of a
+// multi-GB file).  The list is a token stream (the reference reads it with fscanf, so line breaks mean nothing): the
+// byte range is cut into chunks at whitespace, a first pass counts the tokens of every chunk, the prefix sum tells
+// every chunk which of its tokens starts an entry, and each thread then converts its entries -- running past its
+// chunk's end to finish the last one -- into their final positions: file order is preserved exactly.  Any
+// irregularity (a token that does not parse, an index out of range, too few tokens) makes the caller fall back to
+// the sequential loop, which reproduces the reference's behaviour entry by entry.
+bool parse_entries_parallel(const char *p, const char *end, long NZ, Field field, long M, long N, bool mirrored,
+                            int32_t *ri, int32_t *ci, double *v)
+{
+    const size_t bytes = (size_t)(end - p);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("SBLAS_LOADER_THREADS")) nt = (unsigned)atoi(e);
+    if (nt > 32) nt = 32;
+    size_t min_bytes = 64u << 20; // below this the sequential loop is as fast as starting threads
+    if (const char *e = getenv("SBLAS_LOADER_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10); // (tests)
+    if (nt < 2 || bytes < min_bytes || NZ < (long)nt) return false;
+    const int tpe = field == F_PATTERN ? 2 : field == F_COMPLEX ? 4 : 3;
+    // chunk starts, moved forward to the first byte after a whitespace character (so that no token is cut)
+    std::vector<const char *> cb(nt + 1);
+    cb[0] = p;
+    cb[nt] = end;
+    for (unsigned t = 1; t < nt; ++t) {
+        const char *q = p + bytes / nt * t;
+        while (q < end && !isspace((unsigned char)*q)) ++q;
+        cb[t] = q;
+    }
+    std::vector<long long> ntok(nt, 0);
+    auto count = [&](unsigned t) {
+        long long c = 0;
+        bool in = false;
+        for (const char *q = cb[t]; q < cb[t + 1]; ++q) {
+            const bool ws = isspace((unsigned char)*q);
+            c += (!ws && !in);
+            in = !ws;
+        }
+        ntok[t] = c;
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(count, t);
+        for (auto &x : th) x.join();
+    }
+    std::vector<long long> first(nt + 1, 0); // tokens in front of chunk t
+    for (unsigned t = 0; t < nt; ++t) first[t + 1] = first[t] + ntok[t];
+    if (first[nt] < (long long)NZ * tpe) return false;
+    std::atomic<bool> bad{false};
+    auto convert = [&](unsigned t) {
+        // first entry that STARTS in this chunk, and one past the last
+        long long e0 = (first[t] + tpe - 1) / tpe, e1 = (first[t + 1] + tpe - 1) / tpe;
+        if (e1 > NZ) e1 = NZ;
+        if (e0 >= e1) return;
+        const char *q = cb[t];
+        for (long long skip = e0 * tpe - first[t]; skip > 0; --skip) { // tokens of an entry the chunk before finishes
+            q = skip_ws(q, end);
+            q = token_end(q, end);
+        }
+        for (long long e = e0; e < e1; ++e) {
+            if (!parse_entry(q, end, field, M, N, mirrored, ri[(size_t)e], ci[(size_t)e], v[(size_t)e])) {
+                bad.store(true);
+                return;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(convert, t);
+        for (auto &x : th) x.join();
+    }
+    return !bad.load();
+}
+
+// SBLAS_LOADER_TIMING=1: phase times of a parse on stderr (tools/loader_bench.py)
+struct PhaseClock {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    PhaseClock() : on(getenv("SBLAS_LOADER_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  loader: %-28s %.2f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+
 int parse_file(const char *path, Parsed &out)
 {
+    PhaseClock clock;
     FILE *f = fopen(path, "rb");
     if (!f) return SBLAS_E_IO;
     struct stat st;
     if (fstat(fileno(f), &st) != 0) { fclose(f); return SBLAS_E_IO; }
-    std::vector<char> buf((size_t)st.st_size + 1);
-    const size_t got = fread(buf.data(), 1, (size_t)st.st_size, f);
+    // (plain arrays, not std::vector: a vector would zero-fill -- and page in -- a gigabyte that fread overwrites)
+    std::unique_ptr<char[]> buf(new char[(size_t)st.st_size + 1]);
+    const size_t got = fread(buf.get(), 1, (size_t)st.st_size, f);
     fclose(f);
     buf[got] = '\0';
-    const char *p = buf.data(), *end = buf.data() + got;
+    const char *p = buf.get(), *end = buf.get() + got;
+    clock.lap("read file");
 
     // banner (mmio.h:254-337): five tokens on the first line, the last four case-insensitive
     const char *eol = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -199,30 +317,16 @@ int parse_file(const char *path, Parsed &out)
     }
     if (M < 0 || N < 0 || NZ < 0 || M > 0x7ffffffe || N > 0x7fffffff || NZ > 0x7fffffff) return SBLAS_E_IO;
 
-    std::vector<int32_t> ri((size_t)NZ), ci((size_t)NZ);
-    std::vector<double> v((size_t)NZ);
+    // (uninitialised: the tokeniser threads touch their own parts first)
+    std::unique_ptr<int32_t[]> ri(new int32_t[(size_t)NZ + 1]), ci(new int32_t[(size_t)NZ + 1]);
+    std::unique_ptr<double[]> v(new double[(size_t)NZ + 1]);
     std::vector<int32_t> rowptr((size_t)M + 1, 0);
-    for (long e = 0; e < NZ; ++e) {
-        long i = 0, j = 0;
-        double re = 1.0;
-        if (!parse_int(p, end, i) || !parse_int(p, end, j)) return SBLAS_E_IO;
-        if (field == F_REAL) {
-            if (!parse_real(p, end, re)) return SBLAS_E_IO;
-        } else if (field == F_COMPLEX) {
-            double im;
-            if (!parse_real(p, end, re) || !parse_real(p, end, im)) return SBLAS_E_IO; // imaginary part dropped
-        } else if (field == F_INTEGER) {
-            long iv;
-            if (!parse_int(p, end, iv)) return SBLAS_E_IO;
-            re = (double)(int)iv;
-        }
-        if (i < 1 || i > M || j < 1 || j > N) return SBLAS_E_IO; // the reference would write out of bounds
-        if (mirrored && i != j && (j > M || i > N)) return SBLAS_E_IO;
-        ri[(size_t)e] = (int32_t)(i - 1);
-        ci[(size_t)e] = (int32_t)(j - 1);
-        v[(size_t)e] = re;
-        rowptr[(size_t)(i - 1)]++;
+    if (!parse_entries_parallel(p, end, NZ, field, M, N, mirrored, ri.get(), ci.get(), v.get())) {
+        for (long e = 0; e < NZ; ++e)
+            if (!parse_entry(p, end, field, M, N, mirrored, ri[(size_t)e], ci[(size_t)e], v[(size_t)e])) return SBLAS_E_IO;
     }
+    clock.lap("tokenise entries");
+    for (long e = 0; e < NZ; ++e) rowptr[(size_t)ri[(size_t)e]]++;
     if (mirrored)
         for (long e = 0; e < NZ; ++e)
             if (ri[(size_t)e] != ci[(size_t)e]) rowptr[(size_t)ci[(size_t)e]]++;
@@ -249,6 +353,7 @@ int parse_file(const char *path, Parsed &out)
             out.val[(size_t)at] = v[(size_t)e];
         }
     }
+    clock.lap("count, scan, scatter");
     out.rowptr.swap(rowptr);
     out.rows = (int32_t)M;
     out.cols = (int32_t)N;

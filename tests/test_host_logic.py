@@ -247,3 +247,48 @@ def test_host_rand0to1_is_the_reference_initialiser(sblas, oracle):
     assert B[0] == g["B_first"] and B[1] == g["B_second"] and B[-1] == g["B_last"]
     assert (B == oracle.rand0to1(85 * 64)).all()
     assert len(sblas.rand0to1(0)) == 0
+
+
+@pytest.mark.parametrize("field", ["real", "pattern", "integer", "complex"])
+@pytest.mark.parametrize("symmetry", ["general", "symmetric"])
+def test_loader_parallel_tokenizer_matches_the_sequential_parse(sblas, tmp_path, monkeypatch, field, symmetry):
+    """Large files are tokenised by several threads (chunks cut at whitespace, entries re-aligned by a token count):
+    the arrays must be bit-identical to the single-threaded parse, whatever the layout of the token stream -- several
+    entries per line, entries broken across lines, tabs, blank lines -- and a bad token must still be an error."""
+    rng = np.random.default_rng(7)
+    M, N, NZ = 300, 257, 20000
+    toks = []
+    for _ in range(NZ):
+        i = int(rng.integers(1, M + 1))
+        j = int(rng.integers(1, (i if symmetry == "symmetric" else N) + 1))
+        e = [str(i), str(j)]
+        if field == "real":
+            e.append(repr(float(rng.standard_normal())))
+        elif field == "integer":
+            e.append(str(int(rng.integers(-50, 50))))
+        elif field == "complex":
+            e += ["%.17g" % rng.standard_normal(), "%.3e" % rng.standard_normal()]
+        toks += e
+    seps = rng.choice([" ", "\n", "\t", "  ", "\n\n", " \n"], len(toks))
+    body = "".join(t + s_ for t, s_ in zip(toks, seps))
+    path = tmp_path / ("m_%s_%s.mtx" % (field, symmetry))
+    path.write_text("%%%%MatrixMarket matrix coordinate %s %s\n%% comment\n%d %d %d\n%s" % (field, symmetry, M, N if symmetry == "general" else M, NZ, body))
+    monkeypatch.setenv("SBLAS_LOADER_MIN_BYTES", "0")
+    out = {}
+    for threads in ("1", "7", "13"):
+        monkeypatch.setenv("SBLAS_LOADER_THREADS", threads)
+        os.utime(path, None)                                   # new mtime: the library caches its last parse
+        out[threads] = sblas.read_mtx(str(path))
+    for threads in ("7", "13"):
+        assert out[threads][:4] == out["1"][:4]
+        for a, b in zip(out[threads][4:], out["1"][4:]):
+            assert a.tobytes() == b.tobytes()
+    # a malformed token in the middle: error on both paths
+    bad = tmp_path / "bad.mtx"
+    mid = len(body) // 2
+    bad.write_text("%%%%MatrixMarket matrix coordinate %s %s\n%d %d %d\n%s" % (field, symmetry, M, M if symmetry == "symmetric" else N, NZ,
+                                                                           body[:mid] + " x7 " + body[mid:]))
+    for threads in ("1", "7"):
+        monkeypatch.setenv("SBLAS_LOADER_THREADS", threads)
+        with pytest.raises(sblas.SblasError):
+            sblas.read_mtx(str(bad))
