@@ -3,15 +3,20 @@
 // SpMM  C = alpha*A*B + beta*C   (stage 1 + stage 2; the launcher at the end of this file picks the kernels)
 //   dense_to_rowmajor_kernel     B (col-major) -> Bt (row-major, zero padded, one all-zero row)          [stage 1]
 //   stage_classify_kernel        stage 1 + classify_panels_kernel in one launch (fused C-ABI entry)
-//   classify_panels_kernel       per row panel: dense enough over its column span for the LDS-tiled kernel?
+//   classify_panels_kernel       per row panel: column span and class (LDS-tiled / direct / matrix cores), shared-rows flag
+//   mfma_vote_kernel             one workgroup: matrix-wide decisions before stage 2 (128+ staged columns)
 //   spmm_window6_kernel<G>       qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA loader waves),
 //                                one DPP row per matrix row, streaming windows of A
 //   spmm_direct_dpp_kernel<GROUPS> all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
+//   spmm_direct_merge_kernel     ... of matrices whose neighbouring rows share column patterns (multi-dof FEM, 128-column
+//                                tiles): three rows per wave, shared Bt loads
+//   (spmm_mfma_kernel, panels of dense 16 x 4 sub-blocks on the fp64 matrix cores: spmm_mfma.hip)
 //   spmm_direct_rows_kernel      direct panels of short-row matrices (< 32 per row): four rows per wave
 //   spmm_rowpanel_narrow_kernel  n <= 8 (sub-wave lane groups; 16 / 32 columns behind SBLAS_SPMM_MIN_LDBT=0)
 //   spmm_rows8_kernel            n <= 8 and rows of 256+ nonzeros on average: a wave per row, eight sums per lane
 // Epilogues and merges
 //   axpby_kernel                 y = beta*y + alpha*x                                        (kernel.h:27-38)
+//   scale_kernel                 C = beta*C (a matrix without nonzeros)
 //   merge_rowblocks_kernel       method-2 / SpMV merge: scatter packed row blocks, apply alpha / beta
 //   sum_replicas_kernel          in-place sum over g buffers that live on ONE device (folded ranks)
 // (SpMV kernels: spmv_kernels.hip.)
