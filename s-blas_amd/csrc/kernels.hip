@@ -222,7 +222,7 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
     // cheap filter first, on the panel's first row alone: the block fill cannot exceed a row's own fill of the 4-column
     // blocks it touches (entries / (4 x distinct blocks)), and that takes one pass over one row.
     bool mfma = false;
-    if (sane && mfma_min_fill <= 1.0f) {
+    if (sane && mfma_min_fill <= 1.0f && last < 0x7fff0000) { // (the kernel's end-of-row sentinel is 0x7fffffff)
         const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
         // (the longest of the first 16 rows: the first row itself may be empty)
         int slen = 0, srow = r0;
