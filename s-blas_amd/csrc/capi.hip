@@ -195,7 +195,22 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
         const int64_t ldbt = chunk_ldbt(cols, n, nj);
         int rc, pre_epoch = 0;
-        if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
+        const int sr = sblas::options().stage_range;
+        // Staging traffic saved if the block's columns span no more than twice its rows, against the extra pass over the
+        // column indices and one more launch (~5 us = 40 MB at staging speed; a quarter of nd24k at N = 128 breaks even,
+        // an eighth of a Queen-like matrix at N = 256 runs 1.5x faster: tools/spmm_shapes.py --block)
+        const bool pays = cols > 2 * rows && (uint64_t)(cols - 2 * rows) * (uint64_t)ldbt * 16ull > (uint64_t)nnz * 8ull + (40ull << 20);
+        if (ldbt >= 64 && ldbt_ok(ldbt, nj) && (sr > 0 || (sr < 0 && pays))) {
+            // a row block (method 2): the row-major copy covers only the rows of B the block's nonzeros refer to
+            DeviceScope scope(dev);
+            if (scope.err != hipSuccess) return SBLAS_E_HIP;
+            const bool direct_only = spmm_variant() == sblas::SPMM_VARIANT_DIRECT_DPP ||
+                                     spmm_variant() == sblas::SPMM_VARIANT_DIRECT_ROWS ||
+                                     spmm_variant() == sblas::SPMM_VARIANT_DIRECT_MERGE;
+            if (sblas::launch_stage_range((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, (int)rows, nnz,
+                                          rowptr, colidx, spmm_variant(), direct_only ? 0 : 1, &pre_epoch) != hipSuccess)
+                return SBLAS_E_HIP;
+        } else if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
             spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
             ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)

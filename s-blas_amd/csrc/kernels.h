@@ -23,8 +23,8 @@ enum {
 };
 constexpr int SPMM_MIN_PANEL_ROWS = 32; // smallest classified panel (the workspace tail has room for rows / 32 panels)
 
-// Workspace layout behind the staging copy Bt ((cols + 1) x ldbt doubles): TAIL_HDR ints, then one int2 (column span) per
-// panel, then one int (class) per panel.
+// Workspace layout behind the staging copy Bt ((cols + 1) x ldbt doubles): TAIL_HDR ints, TAIL_PARTS int2 (partial
+// column ranges of a row block), then one int2 (column span) per panel, then one int (class) per panel.
 enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pass met an Inf / NaN in B
        TAIL_STAGE_EPOCH = 1,  // epoch of the staging pass that wrote Bt
        TAIL_DIRECT_EPOCH = 2, // epoch of the classifier run that left panels to the direct kernel
@@ -33,8 +33,10 @@ enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pas
        TAIL_MERGE_EPOCH = 6,  // epoch of the call whose direct panels go to the row-merging kernel (rows share column patterns)
        TAIL_MFMAD_EPOCH = 5,  // ... and some of them fall back to the DIRECT kernel when B holds a non-finite value
        TAIL_HDR = 16 };
+constexpr int TAIL_PARTS = 1024; // (min, max) column pairs of the column-range pass of a row block (behind the header)
 enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3,
-       PANEL_CLASS_MASK = 0xff, PANEL_SHARED_ROWS = 0x100 /* flag: the panel's leading rows list the same columns */ };
+       PANEL_CLASS_MASK = 0xff, PANEL_SHARED_ROWS = 0x100 /* flag: the panel's leading rows list the same columns */,
+       PANEL_PHASE_SHIFT = 9 /* two bits: (row index where a group of three such rows starts) mod 3 */ };
 constexpr int MFMA_MAX_WAVES = 8; // 16 rows per wave: panels of up to 128 rows (taller panels never take the MFMA kernel)
 size_t workspace_tail_bytes(int64_t rows);
 unsigned long long *panel_stats_device();
@@ -51,6 +53,7 @@ struct Options {
     unsigned long long max_bt_bytes = 0xffffffffull; // SBLAS_SPMM_MAX_BT_BYTES (tests of the column-chunk loop)
     int direct_lds = -1;                  // SBLAS_DIRECT_LDS
     int direct_map = -1;                  // SBLAS_DIRECT_MAP: 1 interleave, 0 contiguous, -1 by span
+    int stage_range = -1;                 // SBLAS_STAGE_RANGE: stage only the rows of B a row block refers to (-1: when the saved staging traffic outweighs the column-range pass)
     int direct_merge = 1;                 // SBLAS_DIRECT_MERGE: 128-column direct panels through the row-merging kernel
     double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
@@ -61,6 +64,9 @@ const Options &options();
 void options_reload();
 void raise_dynamic_lds(const void *fn, size_t bytes);
 
+hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                              int64_t ldbt, int rows, int64_t nnz, const int *rowptr, const int *colidx, int variant,
+                              int classify, int *epoch_out);
 hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb,
                                     double *Bt, int64_t ldbt);
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,

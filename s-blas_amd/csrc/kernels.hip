@@ -102,6 +102,93 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
                stage_epoch);
 }
 
+// Stage 1 of a ROW BLOCK (method 2: rows << cols).  A block of a banded matrix refers to a narrow range of columns,
+// so only that range of B needs a row-major copy: at config 5's shape a rank of eight stages 15 % of B instead of
+// all of it.  colrange_kernel finds the exact range (every column index is read: rows need not be sorted), one
+// (min, max) per workgroup into the span array the classifier fills later; stage_range_kernel folds those and walks
+// the 32-row tiles of the range, plus the tile holding the all-zero row, in a grid-stride loop.  Rows of Bt outside
+// the range keep whatever the workspace held: no nonzero points at them, and no kernel multiplies a row of Bt that
+// no nonzero points at (masked slots go to the zero row).
+__device__ __forceinline__ void colrange_part(int64_t nnz, const int *__restrict__ colidx, int2 *__restrict__ part,
+                                              int block, int nblocks, int2 *red)
+{
+    int lo = INT_MAX, hi = -1;
+    const int64_t stride = (int64_t)nblocks * 1024;
+    for (int64_t i0 = (int64_t)block * 1024 + threadIdx.x; i0 < nnz; i0 += stride) {
+        int c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = (i0 + 256 * u < nnz) ? colidx[i0 + 256 * u] : INT_MAX;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            lo = min(lo, c[u]);
+            hi = max(hi, c[u] == INT_MAX ? -1 : c[u]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_int2(lo, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = min(lo, red[w].x);
+            hi = max(hi, red[w].y);
+        }
+        part[block] = make_int2(lo, hi);
+    }
+}
+__global__ __launch_bounds__(256) void colrange_kernel(int64_t nnz, const int *__restrict__ colidx,
+                                                       int2 *__restrict__ part)
+{
+    __shared__ int2 red[4];
+    colrange_part(nnz, colidx, part, (int)blockIdx.x, (int)gridDim.x, red);
+}
+__global__ __launch_bounds__(256) void stage_range_kernel(int64_t cols, int64_t n, const double *__restrict__ B,
+                                                          int64_t ldb, double *__restrict__ Bt, int64_t ldbt,
+                                                          int *__restrict__ tail, const int2 *__restrict__ part,
+                                                          int nparts, int stage_epoch)
+{
+    __shared__ double tile[64][STAGE_K + 1];
+    __shared__ int2 red[4];
+    int lo = INT_MAX, hi = -1;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        const int2 p = part[i];
+        lo = min(lo, p.x);
+        hi = max(hi, p.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_int2(lo, hi);
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        lo = min(lo, red[w].x);
+        hi = max(hi, red[w].y);
+    }
+    lo = max(lo, 0); // indices outside [0, cols) are the caller's error; they must not become wild tile numbers
+    hi = (int)min((int64_t)hi, cols - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tail[TAIL_STAGE_EPOCH] = stage_epoch;
+    const int kz = (int)(cols / STAGE_K); // the tile of the all-zero row (row index cols)
+    int kt0 = lo / STAGE_K, kt1 = hi / STAGE_K;
+    if (hi < lo) kt0 = kz, kt1 = kz;
+    const int extra = (kz > kt1 || kz < kt0) ? 1 : 0;
+    const int ny = (int)((ldbt + 63) / 64);
+    const int64_t total = (int64_t)(kt1 - kt0 + 1 + extra) * ny;
+    for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+        const int ky = (int)(t % ny);
+        int kt = kt0 + (int)(t / ny);
+        if (kt > kt1) kt = kz;
+        // stage_tile's own epoch store fires for tile (0, 0) only; it writes the same value
+        stage_tile(tile, (int64_t)kt * STAGE_K, (int64_t)ky * 64, cols, n, B, ldb, Bt, ldbt, tail, stage_epoch);
+        __syncthreads();
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Stage 2, wide form (ldbt a multiple of 64).
 // Workgroup = 4 waves = one panel of PANEL_ROWS consecutive rows x one 64-column tile of C.
@@ -264,12 +351,16 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                    (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
-    // Do neighbouring rows list the same columns (the rows of one mesh node in a multi-dof FEM matrix)?  Rows 0/1 and
-    // 1/2 of the panel are compared entry by entry; the row-merging direct kernel pays only where they do.
+    // Do neighbouring rows list the same columns (the rows of one mesh node in a multi-dof FEM matrix)?  Rows 0/1, 1/2
+    // and 2/3 of the panel are compared entry by entry; the row-merging direct kernel pays only where they do.  The
+    // three answers also say where a group of three such rows STARTS (a method-2 row block begins anywhere): the row
+    // index of a group start, modulo 3, rides in the class word and the merging kernel lines its waves up with it.
     bool shared = false;
+    int phase = 0;
     if (sane && !window_ok && merge_probe) {
         const int r0 = p * panel_rows;
-        for (int k = 0; k < 2 && !shared; ++k) {
+        bool eqk[3] = {false, false, false};
+        for (int k = 0; k < 3; ++k) {
             if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
             const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
             bool eq = b - a == c2 - b && b > a;
@@ -278,13 +369,17 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                 for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
                 eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
             }
-            shared = eq;
+            eqk[k] = eq;
+            if (k == 1 && eqk[0] && eqk[1]) break; // rows 0..2 are one group
         }
+        shared = eqk[0] || eqk[1] || eqk[2];
+        const int t = (eqk[0] && eqk[1]) ? 0 : (!eqk[0] && eqk[1] && eqk[2]) ? 1 : (eqk[0] && !eqk[1] && eqk[2]) ? 2 : 0;
+        phase = (r0 + t) % 3;
     }
     if (lane == 0) {
         info[p] = last >= first ? make_int2(first, last) : make_int2(1, 0);
         const int c = mfma ? (window_ok ? PANEL_MFMA_W : PANEL_MFMA_D) : (window_ok ? PANEL_WINDOW : PANEL_DIRECT);
-        cls[p] = c | (shared ? PANEL_SHARED_ROWS : 0);
+        cls[p] = c | (shared ? PANEL_SHARED_ROWS : 0) | (phase << PANEL_PHASE_SHIFT);
         // the middle panel's column span: the direct kernels take it as the band width of the matrix when they choose
         // their panel -> XCD map (one writer)
         if (p == npanels / 2) tail[TAIL_BAND] = last >= first ? last - first + 1 : 0;
@@ -334,6 +429,25 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                        reinterpret_cast<unsigned *>(&tile[0][0]) + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
     }
 }
+// The same for a row block: the classifier rides with the column-range pass (both read only A); the staging launch
+// that needs the range follows.
+__global__ __launch_bounds__(256) void colrange_classify_kernel(int64_t nnz, int2 *__restrict__ part, int nparts, int rows,
+                                                               int cols, int npanels, int panel_rows,
+                                                               const int *__restrict__ rowptr,
+                                                               const int *__restrict__ colidx, int max_row_len,
+                                                               float min_density, float mfma_min_fill, int merge_probe,
+                                                               int *__restrict__ tail, int2 *__restrict__ info,
+                                                               int *__restrict__ cls, int epoch)
+{
+    __shared__ unsigned bitmaps[4 * MFMA_BITMAP_WORDS];
+    const int cblocks = (npanels + 3) / 4;
+    if ((int)blockIdx.x >= cblocks)
+        colrange_part(nnz, colidx, part, (int)blockIdx.x - cblocks, nparts, reinterpret_cast<int2 *>(bitmaps));
+    else
+        classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx,
+                       max_row_len, min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch,
+                       bitmaps + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
+}
 // The stage-2 kernels run one after the other, so a matrix whose panels split between the matrix-core kernel and the
 // vector kernels pays for two half-empty launches (block-structured rows at the fill threshold, N = 128: 1.05 ms against
 // 0.63 ms for either kernel alone).  One workgroup therefore settles the matter for the whole matrix before stage 2:
@@ -364,7 +478,7 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
     bool any_direct = false;
     for (int p = threadIdx.x; p < npanels; p += 1024) {
         int c = cls[p] & PANEL_CLASS_MASK;
-        const int flag = cls[p] & PANEL_SHARED_ROWS;
+        const int flag = cls[p] & ~PANEL_CLASS_MASK; // shared-rows flag and group phase stay
         if (demote) {
             if (c == PANEL_MFMA_W) c = PANEL_WINDOW;
             if (c == PANEL_MFMA_D) {
@@ -376,7 +490,7 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
         const int2 sp = info[p];
         if (c == PANEL_DIRECT && sp.x <= sp.y) {
             ++direct;
-            shared += flag != 0;
+            shared += (flag & PANEL_SHARED_ROWS) != 0;
         }
     }
     atomicAdd(&counts[2], direct);
@@ -1014,9 +1128,19 @@ __global__ __launch_bounds__(MERGE_WAVES * 64) void spmm_direct_merge_kernel(
     int p0[MR], len[MR];
     bool mine[MR];
     bool all_mine = true;
+    // A method-2 row block starts anywhere, so groups of three pattern-sharing rows need not start at a multiple of
+    // three: the classifier found where they do (class word), waves 1.. take the groups from there and wave 0 the
+    // rows left over at the two ends of the panel (a group of its own when the phase is 0).
+    static_assert(MERGE_PANEL % MR == 0 && MERGE_PANEL == MERGE_WAVES * MR && MR == 3, "row groups of the merging kernel");
+    int phase = 0;
+    if (cls != nullptr) phase = wave_uniform((cls[min(row0, rows - 1) / info_panel_rows] >> PANEL_PHASE_SHIFT) & 3) % MR;
+    int lr[MR];
+#pragma unroll
+    for (int r = 0; r < MR; ++r)
+        lr[r] = wave > 0 ? phase + MR * (wave - 1) + r : (r < phase ? r : MERGE_PANEL - MR + r);
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-        const int row = row0 + wave * MR + r;
+        const int row = row0 + lr[r];
         mine[r] = row < rows;
         if (cls && mine[r]) {
             mine[r] = owns_direct(tail, cls, row / info_panel_rows);
@@ -1065,9 +1189,9 @@ __global__ __launch_bounds__(MERGE_WAVES * 64) void spmm_direct_merge_kernel(
     }
 #pragma unroll
     for (int r = 0; r < MR; ++r) {
-        if (lane == 0) row_mine[wave * MR + r] = mine[r] ? 1 : 0;
-        ctile[2 * lane][wave * MR + r] = acc[r][0];
-        ctile[2 * lane + 1][wave * MR + r] = acc[r][1];
+        if (lane == 0) row_mine[lr[r]] = mine[r] ? 1 : 0;
+        ctile[2 * lane][lr[r]] = acc[r][0];
+        ctile[2 * lane + 1][lr[r]] = acc[r][1];
     }
     __syncthreads();
     const int nrows = min(MERGE_PANEL, rows - row0);
@@ -1493,6 +1617,7 @@ static void options_parse(Options &o)
     }
     if ((e = getenv("SBLAS_DIRECT_LDS")) && *e) o.direct_lds = atoi(e);
     if ((e = getenv("SBLAS_DIRECT_MERGE")) && *e) o.direct_merge = atoi(e);
+    if ((e = getenv("SBLAS_STAGE_RANGE")) && *e) o.stage_range = atoi(e);
     if ((e = getenv("SBLAS_DIRECT_MAP")) && *e) o.direct_map = !strcmp(e, "interleave") ? 1 : !strcmp(e, "contiguous") ? 0 : -1;
     if ((e = getenv("SBLAS_ROWS8_MIN_AVG")) && *e) o.rows8_min_avg = atof(e);
     if ((e = getenv("SBLAS_SPMM_PANEL_ROWS")) && *e) { /* "<rows>" or "<rows>,<groups>" */
@@ -1577,6 +1702,7 @@ static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts and o
 // The workspace behind the staging copy (kernels.h): header ints, one span per panel, one class per panel.
 struct Tail {
     int *hdr;
+    int2 *parts; // TAIL_PARTS (min, max) pairs of the column-range pass
     int2 *info;
     int *cls;
 };
@@ -1585,14 +1711,15 @@ static Tail tail_of(const double *Bt, int64_t cols, int64_t ldbt, int rows)
     Tail t;
     t.hdr = reinterpret_cast<int *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
     const size_t panels = ((size_t)(rows > 0 ? rows : 0) + SPMM_MIN_PANEL_ROWS - 1) / SPMM_MIN_PANEL_ROWS;
-    t.info = reinterpret_cast<int2 *>(t.hdr + TAIL_HDR);
+    t.parts = reinterpret_cast<int2 *>(t.hdr + TAIL_HDR);
+    t.info = t.parts + TAIL_PARTS;
     t.cls = reinterpret_cast<int *>(t.info + panels);
     return t;
 }
 size_t workspace_tail_bytes(int64_t rows)
 {
     const size_t panels = ((size_t)(rows > 0 ? rows : 0) + SPMM_MIN_PANEL_ROWS - 1) / SPMM_MIN_PANEL_ROWS;
-    return (TAIL_HDR * sizeof(int) + panels * (sizeof(int2) + sizeof(int)) + 31) / 16 * 16; // whole 16-byte units
+    return (TAIL_HDR * sizeof(int) + TAIL_PARTS * sizeof(int2) + panels * (sizeof(int2) + sizeof(int)) + 31) / 16 * 16; // whole 16-byte units
 }
 // block fill from which a panel goes to the matrix cores (fp64 MFMA and fp64 vector FMA have the same peak on gfx950,
 // so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/mfma_fill_sweep.py
@@ -1618,6 +1745,33 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
     int *hdr = reinterpret_cast<int *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
     hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, hdr,
                        g_epoch.fetch_add(1, std::memory_order_relaxed));
+    return hipGetLastError();
+}
+
+// Stage 1 of a row block: only the rows of B its nonzeros refer to.  With classify != 0 the panel classifier rides in
+// the column-range launch and *epoch_out goes to launch_spmm_rowpanel; otherwise *epoch_out = 0.
+hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                              int64_t ldbt, int rows, int64_t nnz, const int *rowptr, const int *colidx, int variant,
+                              int classify, int *epoch_out)
+{
+    const Tail t = tail_of(Bt, cols, ldbt, rows);
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 4095) / 4096, TAIL_PARTS));
+    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    if (classify) {
+        int info_rows = 0, g = 2;
+        gen6_plan(rows, info_rows, g);
+        const int np = (rows + info_rows - 1) / info_rows;
+        hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
+                           nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f,
+                           mfma_min_fill(variant, info_rows, ldbt), (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr,
+                           t.info, t.cls, epoch);
+    } else {
+        hipLaunchKernelGGL(colrange_kernel, dim3(nparts), dim3(256), 0, s, nnz, colidx, t.parts);
+    }
+    const int64_t tiles = ((cols + 1 + STAGE_K - 1) / STAGE_K) * ((ldbt + 63) / 64);
+    hipLaunchKernelGGL(stage_range_kernel, dim3((unsigned)std::min<int64_t>(tiles, 2048)), dim3(256), 0, s, cols, n, B,
+                       ldb, Bt, ldbt, t.hdr, t.parts, nparts, epoch);
+    *epoch_out = classify ? epoch : 0;
     return hipGetLastError();
 }
 

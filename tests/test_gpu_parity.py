@@ -662,6 +662,23 @@ def test_config5_full_size_on_one_gpu(env):
     for r0 in (0, rows // 2, rows - 64):
         oracle.spmm_rows(r0, r0 + 64, rows, rows, N, rp, ci, v, Bh, ref, 3.0, 4.0)
         assert close(got[:, r0:r0 + 64].cpu().numpy(), ref.reshape(N, rows)[:, r0:r0 + 64]), r0
+    # One rank's share of method 2 at g = 8 (row block 5, split by nonzeros): only the block's column range of B is
+    # staged (15 % of it) -- the workspace is poisoned first, the rows outside the range must not reach C.
+    nnz = len(ci)
+    a, b = (int(x) for x in np.searchsorted(rp, [nnz * 5 // 8, nnz * 6 // 8]))
+    m = b - a
+    sub = torch.from_numpy((rp[a:b + 1] - rp[a]).astype(np.int32)).to(dev)
+    ws.fill_(float("nan"))
+    Cb = torch.ones(m * N, dtype=torch.float64, device=dev)
+    sblas.spmm(m, rows, sub, A.colidx[rp[a]:rp[b]], A.val[rp[a]:rp[b]], B, rows, N, 3.0, 4.0, Cb, m, ws)
+    torch.cuda.synchronize()
+    ldbt = 128
+    Bt = ws[: (rows + 1) * ldbt].view(rows + 1, ldbt)
+    lo, hi = int(ci[rp[a]:rp[b]].min()), int(ci[rp[a]:rp[b]].max())
+    assert hi - lo < 0.25 * rows
+    assert bool(torch.isnan(Bt[: lo - 32]).all()) and bool(torch.isnan(Bt[hi + 33: rows - 32]).all())    # never staged
+    for r0 in (a, b - 64):
+        assert torch.equal(Cb.view(N, m)[:, r0 - a:r0 - a + 64], got[:, r0:r0 + 64]), r0   # same kernels, same sums as the full call
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -763,6 +780,81 @@ def test_spmm_windowed_mixed_panels_and_row_blocks(env, variant_env, variant):
     oracle.spmm(300, K, n, *As.h, B, part, 1.0, 0.0)
     want[:, 100:400] += part.reshape(n, 300)
     assert close(Cd.cpu().numpy(), want.reshape(-1))
+
+
+@pytest.fixture
+def stage_range_env():
+    yield from _env_switch("SBLAS_STAGE_RANGE")
+
+
+@pytest.mark.parametrize("variant", ["auto", "dpp", "mfma", "merge"])
+@pytest.mark.parametrize("n", [64, 128, 200])
+@pytest.mark.parametrize("kind", ["banded", "unsorted", "scattered"])
+def test_spmm_row_block_stages_only_the_rows_of_b_it_refers_to(env, variant_env, stage_range_env, variant, n, kind):
+    """A method-2 row block copies only its column range of B to row-major form (chosen by itself when the block is
+    large enough for the saved traffic to matter: config 5's eighths; switched on here).  The workspace is
+    poisoned with NaN first and B holds Inf outside the range: neither may reach C, the rows of the copy outside the
+    range must still hold the poison (they were not staged), and unsorted rows must not shrink the range."""
+    sblas, oracle, torch, dev = env
+    variant_env(variant)
+    stage_range_env("1")
+    K, r0, rows, band = 20000, 9000, 1500, 300
+    rng = np.random.default_rng(77)
+    lens = rng.integers(20, 90, rows)
+    lens[5] = 0
+    rp = np.zeros(rows + 1, np.int64)
+    rp[1:] = np.cumsum(lens)
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(rows):
+        lo, hi = (0, K) if kind == "scattered" else (r0 + r - band, r0 + r + band)
+        c = rng.choice(np.arange(lo, hi), lens[r], replace=False)
+        ci[rp[r]:rp[r + 1]] = c if kind == "unsorted" else np.sort(c)
+    v = rng.standard_normal(rp[-1])
+    A = Dev(torch, dev, rp.astype(np.int32), ci, v, K)
+    B = rng.standard_normal(K * n)
+    Bm = B.reshape(n, K)
+    cmin, cmax = int(ci.min()), int(ci.max())
+    if kind != "scattered":
+        Bm[:, : cmin] = np.inf
+        Bm[:, cmax + 1:] = -np.inf
+    C0 = rng.standard_normal(rows * n)
+    Bd, Cd = torch.from_numpy(B).to(dev), torch.from_numpy(C0.copy()).to(dev)
+    ws = torch.full((sblas.spmm_workspace_bytes(rows, K, len(ci), n) // 8,), float("nan"), dtype=torch.float64, device=dev)
+    sblas.spmm(rows, K, A.rowptr, A.colidx, A.val, Bd, K, n, 1.5, -0.5, Cd, rows, ws)
+    torch.cuda.synchronize()
+    Bo = B.copy().reshape(n, K)
+    if kind != "scattered":                       # the oracle multiplies every entry it meets: give it finite rows
+        Bo[:, : cmin] = 0.0
+        Bo[:, cmax + 1:] = 0.0
+    ref = oracle.spmm(rows, K, n, *A.h, Bo.reshape(-1), C0.copy(), 1.5, -0.5)
+    assert close(Cd.cpu().numpy(), ref)
+    if kind != "scattered":
+        ldbt = int(sblas.lib().sblas_hip_spmm_ldbt(n))
+        Bt = ws[: (K + 1) * ldbt].view(K + 1, ldbt).cpu().numpy()
+        assert np.isnan(Bt[: cmin - 32]).all() and np.isnan(Bt[cmax + 33: K - 32]).all()   # never staged
+        assert np.array_equal(Bt[cmin: cmax + 1, :n], Bo[:, cmin: cmax + 1].T)              # the range, exactly
+        assert not Bt[K].any()                                                              # the all-zero row
+
+
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_spmm_stage_range_switch_on_square_and_block(env, stage_range_env, mode):
+    """SBLAS_STAGE_RANGE=1 sends a full square matrix through the range staging (range = everything), =0 keeps a row
+    block on the whole-B staging: same results either way."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    stage_range_env(mode)
+    rng = np.random.default_rng(5)
+    rp, ci, v = synth.banded(3000, 60, 200, seed=3)
+    A = Dev(torch, dev, rp, ci, v, 3000)
+    for n in (64, 130):
+        B, C0 = rng.standard_normal(3000 * n), rng.standard_normal(3000 * n)
+        got = gpu_spmm(sblas, torch, dev, A, B, 3000, n, 2.0, 0.25, C0, 3000)
+        assert close(got, oracle.spmm(3000, 3000, n, *A.h, B, C0.copy(), 2.0, 0.25))
+        sub = (rp[1000:1501] - rp[1000]).astype(np.int32)
+        As = Dev(torch, dev, sub, ci[rp[1000]:rp[1500]], v[rp[1000]:rp[1500]], 3000)
+        Cs = rng.standard_normal(500 * n)
+        got = gpu_spmm(sblas, torch, dev, As, B, 3000, n, 1.0, 1.0, Cs, 500)
+        assert close(got, oracle.spmm(500, 3000, n, *As.h, B, Cs.copy(), 1.0, 1.0))
 
 
 def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_env):
@@ -1110,6 +1202,29 @@ def test_spmm_kernel_event_hook(env):
         sblas.kernel_events(False)
     ref = oracle.spmm(rows, rows, n, *A.h, B.cpu().numpy(), np.zeros(rows * n), 1.0, 0.0)
     assert close(C.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("variant", ["auto", "merge"])
+@pytest.mark.parametrize("start", [0, 1, 2, 3, 1000, 1001, 1002])
+def test_spmm_row_merging_kernel_on_row_blocks_at_any_offset(env, variant_env, variant, start):
+    """Three rows per mesh node share one column pattern; a method-2 row block starts at any row, so the groups of
+    three start at any offset modulo 3 inside the block.  The row-merging kernel lines its waves up with the groups
+    (phase from the classifier); the result never depends on it.  Also a block whose LAST rows are a cut-off group."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    variant_env(variant)
+    rp, ci, v = synth.queen_like_grid(9000, half_band=1500)
+    K = len(rp) - 1
+    rng = np.random.default_rng(start)
+    for m, n in ((4001, 128), (2500, 256)):
+        a, b = start, start + m
+        sub = (rp[a:b + 1] - rp[a]).astype(np.int32)
+        A = Dev(torch, dev, sub, ci[rp[a]:rp[b]], v[rp[a]:rp[b]], K)
+        B, C0 = rng.standard_normal(K * n), rng.standard_normal(m * n)
+        sblas.panel_census()
+        got = gpu_spmm(sblas, torch, dev, A, B, K, n, 0.5, 2.0, C0, m)
+        assert variant != "auto" or sblas.panel_census()["direct"] > 0      # (the forced kernel does not count panels)
+        assert close(got, oracle.spmm(m, K, n, *A.h, B, C0.copy(), 0.5, 2.0))
 
 
 @pytest.mark.parametrize("n", [64, 200, 256, 300])

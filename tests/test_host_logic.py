@@ -209,10 +209,10 @@ def test_argument_validation_returns_codes_without_a_gpu(sblas):
     assert L.sblas_hip_spmm_ldbt(64) == 64 and L.sblas_hip_spmm_ldbt(65) == 128 and L.sblas_hip_spmm_ldbt(8) == 8
     assert L.sblas_hip_spmm_ldbt(33) == 64 and L.sblas_hip_spmm_ldbt(129) == 256
     assert L.sblas_hip_spmm_ldbt(9) == 64 and L.sblas_hip_spmm_ldbt(32) == 64     # 9..32 columns use the 64-column kernels
-    assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8 + 96   # Bt + zero row; tail: 16 header ints, one span + one class per panel, rounded to 16 bytes
+    assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8 + 96 + 8192   # Bt + zero row; tail: 16 header ints, 1024 column-range pairs, one span + one class per panel, rounded to 16 bytes
     assert b"workspace" in L.sblas_hip_error_string(3)
     # Queen_4147-sized B at N = 256 (8.5 GB row-major) is walked in 128-column chunks: workspace = one chunk
-    assert L.sblas_hip_spmm_csr_f64_i32_workspace(4147110, 4147110, 316548962, 256) == 4147111 * 128 * 8 + (64 + ((4147110 + 31) // 32) * 12 + 31) // 16 * 16
+    assert L.sblas_hip_spmm_csr_f64_i32_workspace(4147110, 4147110, 316548962, 256) == 4147111 * 128 * 8 + (64 + 8192 + ((4147110 + 31) // 32) * 12 + 31) // 16 * 16
     # the stage-2-only entry point cannot chunk: a Bt beyond the 32-bit offset window is refused
     assert L.sblas_hip_spmm_csr_rowmajorB_f64_i32(-1, None, 10, 4147110, 5, one, one, one, one, 256, 256, 1.0, 0.0, one, 10) == 1
 

@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--variants", default="auto")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--block", default="", help="i/g: time row block i of g (split by nonzeros, as method 2 does)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n = args.n
@@ -72,17 +73,26 @@ def main():
     for shape in args.shapes:
         t0 = time.time()
         rows, rp, ci, v = make(shape)
+        K = rows
+        if args.block:
+            i, g = (int(x) for x in args.block.split("/"))
+            cut = np.searchsorted(rp, [len(ci) * i // g, len(ci) * (i + 1) // g])
+            a, b = int(cut[0]), max(int(cut[1]), int(cut[0]) + 1)
+            ci, v = ci[rp[a]:rp[b]], v[rp[a]:rp[b]]
+            rp = (rp[a:b + 1] - rp[a]).astype(np.int32)
+            rows = b - a
+            print("row block %s: rows [%d, %d) of %d" % (args.block, a, b, K))
         nnz = len(ci)
         print("%s: %d rows, %d nnz (%.1f per row), generated in %.1f s" % (shape, rows, nnz, nnz / rows, time.time() - t0), flush=True)
         d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         rowptr, colidx, val = d(rp), d(ci), d(v)
-        Bh = O.rand0to1(rows * n)
+        Bh = O.rand0to1(K * n)
         B = d(Bh)
-        ws = torch.empty(S.spmm_workspace_bytes(rows, rows, nnz, n) // 8, dtype=torch.float64, device=dev)
-        alg = nnz * 12 + (rows + 1) * 4 + 8 * rows * n + 16 * rows * n
+        ws = torch.empty(S.spmm_workspace_bytes(rows, K, nnz, n) // 8, dtype=torch.float64, device=dev)
+        alg = nnz * 12 + (rows + 1) * 4 + 8 * K * n + 16 * rows * n
         r0 = rows // 2
         ref = np.zeros(rows * n)
-        O.spmm_rows(r0, r0 + 32, rows, rows, n, rp, ci, v, Bh, ref, 1.0, 0.0)
+        O.spmm_rows(r0, r0 + 32, rows, K, n, rp, ci, v, Bh, ref, 1.0, 0.0)
         want = ref.reshape(n, rows)[:, r0:r0 + 32]
         times = {vs: [] for vs in variants}
         census, ok = {}, {}
@@ -91,7 +101,7 @@ def main():
                 set_variant(vs)
                 C = torch.zeros(rows * n, dtype=torch.float64, device=dev)
                 S.panel_census()
-                S.spmm(rows, rows, rowptr, colidx, val, B, rows, n, 1.0, 0.0, C, rows, ws)      # warm-up + check
+                S.spmm(rows, K, rowptr, colidx, val, B, K, n, 1.0, 0.0, C, rows, ws)      # warm-up + check
                 census[vs] = S.panel_census()
                 got = C.view(n, rows)[:, r0:r0 + 32].cpu().numpy()
                 ok[vs] = bool(np.allclose(got, want, rtol=1e-10, atol=1e-12))
@@ -99,7 +109,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.steps):
-                    S.spmm(rows, rows, rowptr, colidx, val, B, rows, n, 1.0, 1.0, C, rows, ws)
+                    S.spmm(rows, K, rowptr, colidx, val, B, K, n, 1.0, 1.0, C, rows, ws)
                 e1.record()
                 torch.cuda.synchronize()
                 times[vs].append(e0.elapsed_time(e1) / args.steps)
