@@ -302,6 +302,31 @@ def secondary_queen(args, torch, S, dev, rows=300000, n=256, steps=10):
                                  "traffic_source": src, "algorithmic_bytes_per_launch": alg,
                                  "note": "whole step (staging + stage 2, two 128-column tiles), HIP events"},
                     "oracle_check": ok, "oracle_max_abs_diff": err}
+        if key == "grid":
+            # one rank's share of method 2 at g = 8 (row block 3, split by nonzeros): the call stages only the block's
+            # column range of B, and the row-merging kernel follows the block's row-group phase
+            a, b = (int(x) for x in np.searchsorted(rp, [nnz * 3 // 8, nnz * 4 // 8]))
+            mi = b - a
+            sub_rp = (rp[a:b + 1] - rp[a]).astype(np.int32)
+            sub_ci, sub_v = ci[rp[a]:rp[b]], v[rp[a]:rp[b]]
+            srp = d(sub_rp)
+            Cb = torch.ones(mi * n, dtype=torch.float64, device=dev)
+            bstep = lambda: S.spmm(mi, m, srp, colidx[rp[a]:rp[b]], val[rp[a]:rp[b]], B, m, n, 1.0, 1.0, Cb, mi, ws)
+            for _ in range(3):
+                bstep()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                bstep()
+            e1.record()
+            torch.cuda.synchronize()
+            bms = e0.elapsed_time(e1) / steps
+            bok, berr = check_windows(O, Cb.view(n, mi), mi, m, n, sub_rp, sub_ci, sub_v, Bh, 3 + steps, (0, mi // 2, mi - 64))
+            out[key]["method2_rank_share"] = {"block": "3 of 8 by nonzeros: rows [%d, %d)" % (a, b), "nnz": int(len(sub_ci)),
+                                              "ms_per_step": round(bms, 5),
+                                              "gflops": round(2.0 * len(sub_ci) * n / bms / 1e6, 1),
+                                              "oracle_check": bok, "oracle_max_abs_diff": berr}
+            del srp, Cb
         del rowptr, colidx, val, B, C, ws
         torch.cuda.empty_cache()
     return out
@@ -775,6 +800,9 @@ def main():
                     for key, sec in out["secondary"].items():
                         if not sec["oracle_check"]:
                             failures.append("secondary (%s) does not match the oracle: max diff %g" % (key, sec["oracle_max_abs_diff"]))
+                        share = sec.get("method2_rank_share")
+                        if share and not share["oracle_check"]:
+                            failures.append("secondary (%s) row block does not match the oracle: max diff %g" % (key, share["oracle_max_abs_diff"]))
                 # the product's own merge: all GPUs of the job driven from ONE process (a child of rank 0, so that a
                 # hang on untried hardware paths costs a timeout, not the line); one GPU: folded ranks (g = 4 / 8)
                 ndev = 1 if args.fold_ranks else min(world, torch.cuda.device_count())
