@@ -147,6 +147,38 @@ int sblas_hip_merge_rowblocks_local_f64(int device, void *stream, int64_t M, int
                                         const double *const *src, double alpha, double beta, double *C, int64_t ldc);
 
 /* ---------------------------------------------------------------------------------------
+ * The other value / index types of the reference's templates.  sblas_spmm_csr_v1/_v2 and sblas_spmv_csr_v1 are
+ * templated over <IdxType, DataType> and hand cuSPARSE getCudaDataType<float|double>() and
+ * getCusparseIndexType<int32_t|int64_t>() (utility.h:302-316; spmm.h:109-118, :196-213; spmv.h:64-77, :115-118).
+ * The entry points below take the two types as tags and untyped pointers; <SBLAS_I32, SBLAS_F64> forwards to the
+ * tuned *_f64_i32 functions above, the other three combinations run the plain kernels of typed_kernels.hip (same
+ * semantics, sums in the value type in CSR order; not tuned).  alpha / beta are passed as doubles and converted.
+ * One divergence: the reference's method-2 SpMM all-reduces with ncclDouble whatever DataType is (spmm.h:260-262);
+ * here the merge runs in the value type (as the reference's SpMV does, spmv.h:115-118).
+ * ------------------------------------------------------------------------------------- */
+#define SBLAS_F64 0
+#define SBLAS_F32 1
+#define SBLAS_I32 0
+#define SBLAS_I64 1
+size_t sblas_hip_spmm_csr_workspace(int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz, int64_t n);
+int sblas_hip_spmm_csr(int dev, void *stream, int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz,
+                       const void *rowptr, const void *colidx, const void *val, const void *B, int64_t ldb, int64_t n,
+                       double alpha, double beta, void *C, int64_t ldc, void *workspace, size_t workspace_bytes);
+int sblas_hip_spmv_csr(int dev, void *stream, int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz,
+                       const void *rowptr, const void *colidx, const void *val, const void *x, double alpha,
+                       double beta, void *y);
+/* kernel.h:27-38 in either value type */
+int sblas_hip_axpby(int dev, void *stream, int vtype, int64_t n, double alpha, const void *x, double beta, void *y);
+int sblas_hip_allreduce_sum(void *comm, int vtype, void *const *bufs, void *const *streams, int64_t count);
+int sblas_hip_merge_rowblocks(void *comm, int vtype, int64_t M, int64_t N, const int64_t *start_row,
+                              const int64_t *num_rows, void *const *partial, void *const *gather, double alpha,
+                              double beta, void *const *C, int64_t ldc, void *const *streams);
+/* sblas_partition_nnz (below) for 64-bit row pointers */
+int64_t sblas_partition_nnz_i64(const int64_t *rowptr, int64_t rows, int64_t nnz, int n_gpu, int i_gpu,
+                                int64_t *start_row, int64_t *stop_row, int64_t *nnz_i, int64_t *first_nnz,
+                                int64_t *rebased_rowptr);
+
+/* ---------------------------------------------------------------------------------------
  * Host-side placement arithmetic (pure functions, no GPU needed).
  * ------------------------------------------------------------------------------------- */
 /* csr_findRowIdxUsingNnzIdx, utility.h:292-300 (same answer, O(log M)). */

@@ -148,3 +148,37 @@ def partition_dense(first, g, i):
     o, d = C.c_int(), C.c_int()
     lib().orc_partition_dense(first, g, i, C.byref(o), C.byref(d))
     return o.value, d.value
+
+
+# ---- the other instantiations of the reference's templates (float values and / or 64-bit indices) ----
+_TYPED = {(np.dtype(np.float32), np.dtype(np.int32)): "f32_i32", (np.dtype(np.float64), np.dtype(np.int64)): "f64_i64",
+          (np.dtype(np.float32), np.dtype(np.int64)): "f32_i64"}
+
+
+def _typed_fn(kind, val, rowptr):
+    name = _TYPED[(val.dtype, rowptr.dtype)]
+    fn = getattr(lib(), "orc_%s_csr_%s" % (kind, name))
+    ct = C.c_float if val.dtype == np.float32 else C.c_double
+    ip = np.ctypeslib.ndpointer(rowptr.dtype, flags="C_CONTIGUOUS")
+    vp = np.ctypeslib.ndpointer(val.dtype, flags="C_CONTIGUOUS")
+    fn.restype = None
+    if kind == "spmm":
+        fn.argtypes = [C.c_int64, C.c_int64, C.c_int64, ip, ip, vp, vp, vp, ct, ct]
+    else:
+        fn.argtypes = [C.c_int64, ip, ip, vp, vp, vp, ct, ct]
+    return fn
+
+
+def spmm_typed(M, K, N, rowptr, colidx, val, B, C_, alpha, beta):
+    """sblas_spmm_csr_cpu<IdxType, DataType> for (float32 | float64) x (int32 | int64) arrays; in place on C_."""
+    if val.dtype == np.float64 and rowptr.dtype == np.int32:
+        return spmm(M, K, N, rowptr, colidx, val, B, C_, alpha, beta)
+    _typed_fn("spmm", val, rowptr)(M, K, N, rowptr, colidx, val, B, C_, alpha, beta)
+    return C_
+
+
+def spmv_typed(M, rowptr, colidx, val, x, y, alpha, beta):
+    if val.dtype == np.float64 and rowptr.dtype == np.int32:
+        return spmv(M, rowptr, colidx, val, x, y, alpha, beta)
+    _typed_fn("spmv", val, rowptr)(M, rowptr, colidx, val, x, y, alpha, beta)
+    return y

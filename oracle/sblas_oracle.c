@@ -269,6 +269,34 @@ void orc_spmv_csr(int M, const int *rowptr, const int *colidx, const double *val
     }
 }
 
+/* The same two loops in the other instantiations of the reference's templates -- sblas_spmm_csr_cpu<IdxType, DataType>
+ * (spmm.h:29-68) and sblas_spmv_csr_cpu<IdxType, DataType> (spmv.h:15-31) with DataType float and / or IdxType
+ * int64_t (utility.h:302-316 lists the types the GPU paths map).  `DataType sum = 0` accumulates in the value type. */
+#define ORC_TYPED(NAME, I, T)                                                                                   \
+    void orc_spmm_csr_##NAME(int64_t M, int64_t K, int64_t N, const I *rowptr, const I *colidx, const T *val,   \
+                             const T *B, T *C, T alpha, T beta)                                                \
+    {                                                                                                           \
+        for (int64_t i = 0; i < M; ++i)                                                                         \
+            for (int64_t n = 0; n < N; ++n) {                                                                   \
+                T sum = 0;                                                                                      \
+                for (I j = rowptr[i]; j < rowptr[i + 1]; ++j) sum += val[j] * B[(size_t)n * (size_t)K + (size_t)colidx[j]]; \
+                size_t at = (size_t)n * (size_t)M + (size_t)i;                                                  \
+                C[at] = beta * C[at] + alpha * sum;                                                             \
+            }                                                                                                   \
+    }                                                                                                           \
+    void orc_spmv_csr_##NAME(int64_t M, const I *rowptr, const I *colidx, const T *val, const T *x, T *y,       \
+                             T alpha, T beta)                                                                   \
+    {                                                                                                           \
+        for (int64_t i = 0; i < M; ++i) {                                                                       \
+            T sum = 0;                                                                                          \
+            for (I j = rowptr[i]; j < rowptr[i + 1]; ++j) sum += val[j] * x[colidx[j]];                         \
+            y[i] = beta * y[i] + alpha * sum;                                                                   \
+        }                                                                                                       \
+    }
+ORC_TYPED(f32_i32, int32_t, float)
+ORC_TYPED(f64_i64, int64_t, double)
+ORC_TYPED(f32_i64, int64_t, float)
+
 /* denseVector_plusEqual_denseVector, kernel.h:27-38: y = y*beta + x*alpha. */
 void orc_axpby(size_t n, double alpha, const double *x, double beta, double *y)
 {

@@ -284,4 +284,75 @@ int sblas_hip_axpby_f64(int dev, void *stream, int64_t n, double alpha, const do
                                                                                        : SBLAS_E_HIP;
 }
 
+// ---- the other value / index types (typed_kernels.hip); <int32, fp64> forwards to the tuned entry points above ----
+static bool types_ok(int vtype, int itype)
+{
+    return (vtype == SBLAS_F64 || vtype == SBLAS_F32) && (itype == SBLAS_I32 || itype == SBLAS_I64);
+}
+
+size_t sblas_hip_spmm_csr_workspace(int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz, int64_t n)
+{
+    if (!types_ok(vtype, itype)) return 0;
+    if (vtype == SBLAS_F64 && itype == SBLAS_I32) return sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n);
+    return sblas::typed_spmm_workspace(vtype, cols, n);
+}
+
+int sblas_hip_spmm_csr(int dev, void *stream, int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz,
+                       const void *rowptr, const void *colidx, const void *val, const void *B, int64_t ldb, int64_t n,
+                       double alpha, double beta, void *C, int64_t ldc, void *workspace, size_t workspace_bytes)
+{
+    if (!types_ok(vtype, itype)) return SBLAS_E_INVALID;
+    if (vtype == SBLAS_F64 && itype == SBLAS_I32)
+        return sblas_hip_spmm_csr_f64_i32(dev, stream, rows, cols, nnz, static_cast<const int32_t *>(rowptr),
+                                          static_cast<const int32_t *>(colidx), static_cast<const double *>(val),
+                                          static_cast<const double *>(B), ldb, n, alpha, beta, static_cast<double *>(C),
+                                          ldc, workspace, workspace_bytes);
+    if (rows < 0 || cols < 0 || nnz < 0 || n < 0 || !rowptr || (nnz > 0 && (!colidx || !val))) return SBLAS_E_INVALID;
+    if (itype == SBLAS_I32 && (rows > INT_MAX - 64 || cols > INT_MAX || nnz > INT_MAX)) return SBLAS_E_INVALID;
+    if (rows == 0 || n == 0) return SBLAS_OK;
+    if (!C || ldc < rows) return SBLAS_E_INVALID;
+    if (cols > 0 && (!B || ldb < cols)) return SBLAS_E_INVALID;
+    const size_t need = (cols == 0 || nnz == 0) ? 0 : sblas::typed_spmm_workspace(vtype, cols, n);
+    if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_typed_spmm((hipStream_t)stream, vtype, itype, rows, cols, nnz, rowptr, colidx, val, B, ldb, n, alpha,
+                                    beta, C, ldc, workspace) == hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+int sblas_hip_spmv_csr(int dev, void *stream, int vtype, int itype, int64_t rows, int64_t cols, int64_t nnz,
+                       const void *rowptr, const void *colidx, const void *val, const void *x, double alpha,
+                       double beta, void *y)
+{
+    if (!types_ok(vtype, itype)) return SBLAS_E_INVALID;
+    if (vtype == SBLAS_F64 && itype == SBLAS_I32)
+        return sblas_hip_spmv_csr_f64_i32(dev, stream, rows, cols, nnz, static_cast<const int32_t *>(rowptr),
+                                          static_cast<const int32_t *>(colidx), static_cast<const double *>(val),
+                                          static_cast<const double *>(x), alpha, beta, static_cast<double *>(y));
+    if (rows < 0 || cols < 0 || nnz < 0 || !rowptr || (nnz > 0 && (!colidx || !val))) return SBLAS_E_INVALID;
+    if (itype == SBLAS_I32 && (rows > INT_MAX - 64 || cols > INT_MAX || nnz > INT_MAX)) return SBLAS_E_INVALID;
+    if (rows == 0) return SBLAS_OK;
+    if (!y || (cols > 0 && !x)) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_typed_spmv((hipStream_t)stream, vtype, itype, rows, rowptr, colidx, val, x, alpha, beta, y) ==
+                   hipSuccess
+               ? SBLAS_OK
+               : SBLAS_E_HIP;
+}
+
+int sblas_hip_axpby(int dev, void *stream, int vtype, int64_t n, double alpha, const void *x, double beta, void *y)
+{
+    if (vtype == SBLAS_F64)
+        return sblas_hip_axpby_f64(dev, stream, n, alpha, static_cast<const double *>(x), beta, static_cast<double *>(y));
+    if (vtype != SBLAS_F32 || n < 0) return SBLAS_E_INVALID;
+    if (n == 0) return SBLAS_OK;
+    if (!x || !y) return SBLAS_E_INVALID;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    return sblas::launch_typed_axpby((hipStream_t)stream, vtype, n, alpha, x, beta, y) == hipSuccess ? SBLAS_OK : SBLAS_E_HIP;
+}
+
 } // extern "C"

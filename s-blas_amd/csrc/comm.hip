@@ -21,6 +21,7 @@ typedef int (*fn_CommDestroy)(rcclComm_t);
 typedef int (*fn_AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t);
 typedef int (*fn_SendRecv)(void *, size_t, int, int, rcclComm_t, hipStream_t); // ncclSend / ncclRecv (rccl.h)
 typedef int (*fn_Group)(void);
+constexpr int RCCL_FLOAT32 = 7; // ncclFloat32 / ncclFloat, rccl.h:466
 constexpr int RCCL_FLOAT64 = 8; // ncclFloat64 / ncclDouble, rccl.h:467
 constexpr int RCCL_SUM = 0;     // ncclSum, rccl.h:448
 
@@ -135,8 +136,9 @@ extern "C" void sblas_hip_comm_release_all(void)
     g_sets.clear();
 }
 
-extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void *const *streams, int64_t count)
+extern "C" int sblas_hip_allreduce_sum(void *comm, int vtype, void *const *bufs, void *const *streams, int64_t count)
 {
+    if (vtype != SBLAS_F64 && vtype != SBLAS_F32) return SBLAS_E_INVALID;
     if (!comm || !bufs || count < 0) return SBLAS_E_INVALID;
     if (count == 0) return SBLAS_OK;
     CommSet &s = *static_cast<CommSet *>(comm);
@@ -152,15 +154,13 @@ extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void
         // then order every other stream after the sum.
         if (hipSetDevice(s.devs[0]) != hipSuccess) return SBLAS_E_HIP;
         hipStream_t s0 = streams ? (hipStream_t)streams[0] : nullptr;
-        sblas::ReplicaPtrs p{};
-        for (int i = 0; i < g; ++i) p.p[i] = bufs[i];
         for (int i = 1; i < g && rc == SBLAS_OK; ++i) {
             hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
             if (si == s0) continue;
             if (hipEventRecord(s.events[i], si) != hipSuccess || hipStreamWaitEvent(s0, s.events[i], 0) != hipSuccess)
                 rc = SBLAS_E_HIP;
         }
-        if (rc == SBLAS_OK && sblas::launch_sum_replicas(s0, p, g, count) != hipSuccess) rc = SBLAS_E_HIP;
+        if (rc == SBLAS_OK && sblas::launch_typed_sum_replicas(s0, vtype, bufs, g, count) != hipSuccess) rc = SBLAS_E_HIP;
         if (rc == SBLAS_OK && hipEventRecord(s.events[0], s0) != hipSuccess) rc = SBLAS_E_HIP;
         for (int i = 1; i < g && rc == SBLAS_OK; ++i) {
             hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
@@ -173,13 +173,18 @@ extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void
         if (r.GroupStart() != 0) return SBLAS_E_RCCL;
         for (int i = 0; i < g; ++i) {
             if (hipSetDevice(s.devs[i]) != hipSuccess) { rc = SBLAS_E_HIP; break; }
-            if (r.AllReduce(bufs[i], bufs[i], (size_t)count, RCCL_FLOAT64, RCCL_SUM, s.comms[i],
+            if (r.AllReduce(bufs[i], bufs[i], (size_t)count, vtype == SBLAS_F32 ? RCCL_FLOAT32 : RCCL_FLOAT64, RCCL_SUM, s.comms[i],
                             streams ? (hipStream_t)streams[i] : nullptr) != 0) { rc = SBLAS_E_RCCL; break; }
         }
         if (r.GroupEnd() != 0 && rc == SBLAS_OK) rc = SBLAS_E_RCCL;
     }
     (void)hipSetDevice(prev);
     return rc;
+}
+
+extern "C" int sblas_hip_allreduce_sum_f64(void *comm, double *const *bufs, void *const *streams, int64_t count)
+{
+    return sblas_hip_allreduce_sum(comm, SBLAS_F64, reinterpret_cast<void *const *>(bufs), streams, count);
 }
 
 extern "C" int sblas_hip_merge_rowblocks_local_f64(int device, void *stream, int64_t M, int64_t N, int g,
@@ -201,11 +206,13 @@ extern "C" int sblas_hip_merge_rowblocks_local_f64(int device, void *stream, int
                : SBLAS_E_HIP;
 }
 
-extern "C" int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, const int64_t *start_row,
-                                             const int64_t *num_rows, double *const *partial, double *const *gather,
-                                             double alpha, double beta, double *const *C, int64_t ldc,
-                                             void *const *streams)
+extern "C" int sblas_hip_merge_rowblocks(void *comm, int vtype, int64_t M, int64_t N, const int64_t *start_row,
+                                         const int64_t *num_rows, void *const *partial, void *const *gather, double alpha,
+                                         double beta, void *const *C, int64_t ldc, void *const *streams)
 {
+    if (vtype != SBLAS_F64 && vtype != SBLAS_F32) return SBLAS_E_INVALID;
+    const size_t esz = vtype == SBLAS_F32 ? 4 : 8;
+    const int rccl_type = vtype == SBLAS_F32 ? RCCL_FLOAT32 : RCCL_FLOAT64;
     if (!comm || !start_row || !num_rows || !partial || !C || M < 0 || N < 0 || ldc < M) return SBLAS_E_INVALID;
     if (M == 0 || N == 0) return SBLAS_OK;
     CommSet &s = *static_cast<CommSet *>(comm);
@@ -243,8 +250,9 @@ extern "C" int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, c
             for (int q = 0; q < g && rc == SBLAS_OK; ++q) {
                 if (q == i) continue;
                 const size_t mine = (size_t)num_rows[i] * (size_t)N, theirs = (size_t)num_rows[q] * (size_t)N;
-                if (mine && r.Send(partial[i], mine, RCCL_FLOAT64, q, s.comms[i], si) != 0) rc = SBLAS_E_RCCL;
-                if (theirs && rc == SBLAS_OK && r.Recv(gather[i] + off[q], theirs, RCCL_FLOAT64, q, s.comms[i], si) != 0)
+                if (mine && r.Send(partial[i], mine, rccl_type, q, s.comms[i], si) != 0) rc = SBLAS_E_RCCL;
+                if (theirs && rc == SBLAS_OK &&
+                    r.Recv(static_cast<char *>(gather[i]) + off[q] * esz, theirs, rccl_type, q, s.comms[i], si) != 0)
                     rc = SBLAS_E_RCCL;
             }
         }
@@ -252,12 +260,27 @@ extern "C" int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, c
     }
     for (int i = 0; i < g && rc == SBLAS_OK; ++i) {
         if (hipSetDevice(s.devs[i]) != hipSuccess) { rc = SBLAS_E_HIP; break; }
-        const double *src[sblas::MAX_REPLICAS];
-        for (int q = 0; q < g; ++q) src[q] = (q == i || !exchange) ? partial[q] : gather[i] + off[q];
-        if (sblas::launch_merge_rowblocks(streams ? (hipStream_t)streams[i] : nullptr, M, N, g, src, start_row, num_rows,
-                                          alpha, beta, C[i], ldc) != hipSuccess)
-            rc = SBLAS_E_HIP;
+        const void *src[sblas::MAX_REPLICAS];
+        for (int q = 0; q < g; ++q)
+            src[q] = (q == i || !exchange) ? partial[q] : static_cast<const void *>(static_cast<char *>(gather[i]) + off[q] * esz);
+        hipStream_t si = streams ? (hipStream_t)streams[i] : nullptr;
+        const hipError_t e =
+            vtype == SBLAS_F64
+                ? sblas::launch_merge_rowblocks(si, M, N, g, reinterpret_cast<const double *const *>(src), start_row, num_rows,
+                                                alpha, beta, static_cast<double *>(C[i]), ldc)
+                : sblas::launch_typed_merge_rowblocks(si, vtype, M, N, g, src, start_row, num_rows, alpha, beta, C[i], ldc);
+        if (e != hipSuccess) rc = SBLAS_E_HIP;
     }
     (void)hipSetDevice(prev);
     return rc;
+}
+
+extern "C" int sblas_hip_merge_rowblocks_f64(void *comm, int64_t M, int64_t N, const int64_t *start_row,
+                                             const int64_t *num_rows, double *const *partial, double *const *gather,
+                                             double alpha, double beta, double *const *C, int64_t ldc,
+                                             void *const *streams)
+{
+    return sblas_hip_merge_rowblocks(comm, SBLAS_F64, M, N, start_row, num_rows, reinterpret_cast<void *const *>(partial),
+                                     reinterpret_cast<void *const *>(gather), alpha, beta,
+                                     reinterpret_cast<void *const *>(C), ldc, streams);
 }

@@ -58,6 +58,33 @@ extern "C" int64_t sblas_partition_nnz(const int32_t *rowptr, int32_t rows, int3
     return num;
 }
 
+// The same partition for CsrSparseMatrix<int64_t, T> (the reference's sync2gpu is one template, matrix.h:356-375).
+extern "C" int64_t sblas_partition_nnz_i64(const int64_t *rowptr, int64_t rows, int64_t nnz, int n_gpu, int i_gpu,
+                                           int64_t *start_row, int64_t *stop_row, int64_t *nnz_i, int64_t *first_nnz,
+                                           int64_t *rebased_rowptr)
+{
+    if (!rowptr || rows <= 0 || nnz <= 0 || n_gpu <= 0 || i_gpu < 0 || i_gpu >= n_gpu) return -1;
+    const int64_t avg = (nnz + n_gpu - 1) / n_gpu;
+    const int64_t lo = (int64_t)i_gpu * avg;
+    const int64_t hi = std::min<int64_t>((int64_t)(i_gpu + 1) * avg, nnz);
+    if (lo >= hi) return -2;
+    // row of a nonzero: the last row whose first nonzero is not beyond it (utility.h:292-300)
+    auto row_of = [&](int64_t k) { return (int64_t)(std::upper_bound(rowptr, rowptr + rows + 1, k) - rowptr) - 1; };
+    const int64_t s = row_of(lo), e = row_of(hi - 1);
+    if (s < 0 || e < 0 || s >= rows || e >= rows) return -3;
+    if (start_row) *start_row = s;
+    if (stop_row) *stop_row = e;
+    if (nnz_i) *nnz_i = hi - lo;
+    if (first_nnz) *first_nnz = lo;
+    const int64_t num = e - s + 2;
+    if (rebased_rowptr) {
+        rebased_rowptr[0] = 0;
+        for (int64_t k = 1; k < num - 1; ++k) rebased_rowptr[k] = rowptr[s + k] - lo;
+        rebased_rowptr[num - 1] = hi - lo;
+    }
+    return num;
+}
+
 // The dense initialiser of the reference's DenseMatrix / DenseVector constructors (matrix.h:519-528, :663-672):
 // srand(seed) and rand() / RAND_MAX in storage order -- the C library's generator, so callers outside C++ (bench.py)
 // can build the very B the reference's drivers multiply.  Not re-entrant (global libc state), like the reference.

@@ -87,4 +87,20 @@ hipError_t launch_merge_rowblocks(hipStream_t s, int64_t M, int64_t N, int g, co
                                   const int64_t *start, const int64_t *nrows, double alpha, double beta, double *C,
                                   int64_t ldc);
 
+// typed_kernels.hip: the value / index types besides <int32, fp64> (reference utility.h:302-316)
+enum { VT_F64 = 0, VT_F32 = 1 };
+enum { IT_I32 = 0, IT_I64 = 1 };
+int64_t typed_spmm_ldbt(int64_t n);
+size_t typed_spmm_workspace(int vt, int64_t cols, int64_t n);
+hipError_t launch_typed_spmm(hipStream_t s, int vt, int it, int64_t rows, int64_t cols, int64_t nnz, const void *rowptr,
+                             const void *colidx, const void *val, const void *B, int64_t ldb, int64_t n, double alpha,
+                             double beta, void *C, int64_t ldc, void *ws);
+hipError_t launch_typed_spmv(hipStream_t s, int vt, int it, int64_t rows, const void *rowptr, const void *colidx,
+                             const void *val, const void *x, double alpha, double beta, void *y);
+hipError_t launch_typed_axpby(hipStream_t s, int vt, int64_t n, double alpha, const void *x, double beta, void *y);
+hipError_t launch_typed_sum_replicas(hipStream_t s, int vt, void *const *bufs, int g, int64_t n);
+hipError_t launch_typed_merge_rowblocks(hipStream_t s, int vt, int64_t M, int64_t N, int g, const void *const *src,
+                                        const int64_t *start_row, const int64_t *num_rows, double alpha, double beta,
+                                        void *C, int64_t ldc);
+
 } // namespace sblas

@@ -329,16 +329,26 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
             sblas_detail::replicate_async(n_gpu, csrColIdx, (size_t)nnz, csrColIdx_gpu);
             sblas_detail::replicate_async(n_gpu, csrVal, (size_t)nnz, csrVal_gpu);
         } else if (policy == segment) {
-            static_assert(sizeof(IdxType) == 4, "segmenting needs 32-bit row pointers");
             SAFE_ALOC_HOST(nnz_gpu, n_gpu * sizeof(IdxType));
             SAFE_ALOC_HOST(starting_row_gpu, n_gpu * sizeof(IdxType));
             SAFE_ALOC_HOST(stoping_row_gpu, n_gpu * sizeof(IdxType));
             std::vector<IdxType *> rebased(n_gpu, (IdxType *)NULL); // pinned staging, freed after the drain
+            // the partition arithmetic lives behind the C ABI, once per index width
+            auto split = [&](unsigned i, int64_t *s, int64_t *e, int64_t *k, int64_t *first, IdxType *out) -> int64_t {
+                if (sizeof(IdxType) == 4) {
+                    int32_t s4 = 0, e4 = 0, k4 = 0;
+                    const int64_t num = sblas_partition_nnz((const int32_t *)csrRowPtr, (int32_t)height, (int32_t)nnz,
+                                                            (int)n_gpu, (int)i, &s4, &e4, &k4, first, (int32_t *)out);
+                    *s = s4, *e = e4, *k = k4;
+                    return num;
+                }
+                return sblas_partition_nnz_i64((const int64_t *)csrRowPtr, (int64_t)height, (int64_t)nnz, (int)n_gpu, (int)i,
+                                               s, e, k, first, (int64_t *)out);
+            };
             for (unsigned i = 0; i < n_gpu; ++i) {
-                int32_t s = 0, e = 0, k = 0;
+                int64_t s = 0, e = 0, k = 0;
                 int64_t first = 0;
-                const int64_t num = sblas_partition_nnz((const int32_t *)csrRowPtr, (int32_t)height, (int32_t)nnz,
-                                                        (int)n_gpu, (int)i, &s, &e, &k, &first, NULL);
+                const int64_t num = split(i, &s, &e, &k, &first, (IdxType *)NULL);
                 if (num < 0) {
                     fprintf(stderr, "S-BLAS: cannot split %ld nonzeros over %u GPUs (GPU %u would own none)\n",
                             (long)nnz, n_gpu, i);
@@ -348,8 +358,7 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
                 stoping_row_gpu[i] = (IdxType)e;
                 nnz_gpu[i] = (IdxType)k;
                 SAFE_ALOC_HOST(rebased[i], (size_t)num * sizeof(IdxType));
-                sblas_partition_nnz((const int32_t *)csrRowPtr, (int32_t)height, (int32_t)nnz, (int)n_gpu, (int)i,
-                                    NULL, NULL, NULL, NULL, (int32_t *)rebased[i]);
+                split(i, &s, &e, &k, &first, rebased[i]);
                 csrRowPtr_gpu[i] = sblas_detail::to_device_async(i, rebased[i], (size_t)num);
                 csrColIdx_gpu[i] = sblas_detail::to_device_async(i, csrColIdx + first, (size_t)k);
                 csrVal_gpu[i] = sblas_detail::to_device_async(i, csrVal + first, (size_t)k);
@@ -530,11 +539,10 @@ template <typename IdxType, typename DataType> class DenseMatrix {
         const size_t cnt = get_mtx_num();
         for (unsigned i = 0; i < n_gpu; ++i) {
             CUDA_SAFE_CALL(cudaSetDevice((int)i));
-            if (std::is_same<DataType, double>::value) {
-                sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, sblas_rt::stream(i), (int64_t)cnt, (double)alpha,
-                                                         (const double *)dm.val_gpu[i], (double)beta,
-                                                         (double *)val_gpu[i]),
-                                     "sblas_hip_axpby_f64");
+            if (std::is_same<DataType, double>::value || std::is_same<DataType, float>::value) {
+                sblas_rt::must_sblas(sblas_hip_axpby(-1, sblas_rt::stream(i), sblas_rt::vtype_of<DataType>("axpby"),
+                                                     (int64_t)cnt, (double)alpha, dm.val_gpu[i], (double)beta, val_gpu[i]),
+                                     "sblas_hip_axpby");
             } else {
                 const unsigned blocks = (unsigned)std::min<size_t>((cnt + NUM_THREADS_PER_BLK - 1) / NUM_THREADS_PER_BLK, 2048);
                 hipLaunchKernelGGL((denseVector_plusEqual_denseVector<size_t, DataType>), dim3(blocks ? blocks : 1),
@@ -631,11 +639,10 @@ template <typename IdxType, typename DataType> class DenseVector {
         const size_t cnt = get_vec_length();
         for (unsigned i = 0; i < n_gpu; ++i) {
             CUDA_SAFE_CALL(cudaSetDevice((int)i));
-            if (std::is_same<DataType, double>::value) {
-                sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, sblas_rt::stream(i), (int64_t)cnt, (double)alpha,
-                                                         (const double *)dv.val_gpu[i], (double)beta,
-                                                         (double *)val_gpu[i]),
-                                     "sblas_hip_axpby_f64");
+            if (std::is_same<DataType, double>::value || std::is_same<DataType, float>::value) {
+                sblas_rt::must_sblas(sblas_hip_axpby(-1, sblas_rt::stream(i), sblas_rt::vtype_of<DataType>("axpby"),
+                                                     (int64_t)cnt, (double)alpha, dv.val_gpu[i], (double)beta, val_gpu[i]),
+                                     "sblas_hip_axpby");
             } else {
                 const unsigned blocks = (unsigned)std::min<size_t>((cnt + NUM_THREADS_PER_BLK - 1) / NUM_THREADS_PER_BLK, 2048);
                 hipLaunchKernelGGL((denseVector_plusEqual_denseVector<size_t, DataType>), dim3(blocks ? blocks : 1),

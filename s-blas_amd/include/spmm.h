@@ -55,13 +55,6 @@ void sblas_spmm_csr_cpu(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxT
 
 namespace sblas_detail {
 
-template <typename IdxType, typename DataType> inline void require_f64_i32(const char *who)
-{
-    if (!(std::is_same<DataType, double>::value && sizeof(IdxType) == 4)) {
-        cerr << who << ": the MI355X kernels are built for int32 indices and fp64 values" << endl;
-        exit(-1);
-    }
-}
 
 template <typename IdxType, typename DataType>
 inline void require_col_major(const char *who, DenseMatrix<IdxType, DataType> *pB, DenseMatrix<IdxType, DataType> *pC)
@@ -88,7 +81,7 @@ void sblas_spmm_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     assert((pA->height) == (pC->height));
     assert((pB->width) == (pC->width));
     sblas_detail::require_col_major("SBLAS_SPMM_CSR_V1", pB, pC);
-    sblas_detail::require_f64_i32<IdxType, DataType>("SBLAS_SPMM_CSR_V1");
+    const int vt = sblas_rt::vtype_of<DataType>("SBLAS_SPMM_CSR_V1"), it = sblas_rt::itype_of<IdxType>("SBLAS_SPMM_CSR_V1");
     assert(pA->policy == replicate && pB->policy == segment && pC->policy == segment);
     cout << "sblas_spmm_csr_v1 ready to start" << endl;
     const int64_t M = pA->height, K = pA->width, nnz = pA->nnz;
@@ -97,14 +90,12 @@ void sblas_spmm_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         printf("gpu-%d m:%d, n:%ld, k:%d\n", i, (int)pA->height, (long)n_i, (int)pA->width);
         if (n_i == 0) continue;
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
-        const size_t ws_bytes = sblas_hip_spmm_csr_f64_i32_workspace(M, K, nnz, n_i);
+        const size_t ws_bytes = sblas_hip_spmm_csr_workspace(vt, it, M, K, nnz, n_i);
         void *ws = sblas_rt::workspace(i, ws_bytes);
-        sblas_rt::must_sblas(
-            sblas_hip_spmm_csr_f64_i32(-1, sblas_rt::stream(i), M, K, nnz, (const int32_t *)pA->csrRowPtr_gpu[i],
-                                       (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
-                                       (const double *)pB->val_gpu[i], K, n_i, (double)alpha, (double)beta,
-                                       (double *)pC->val_gpu[i], M, ws, ws_bytes),
-            "sblas_hip_spmm_csr_f64_i32");
+        sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, sblas_rt::stream(i), vt, it, M, K, nnz, pA->csrRowPtr_gpu[i],
+                                                pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, n_i,
+                                                (double)alpha, (double)beta, pC->val_gpu[i], M, ws, ws_bytes),
+                             "sblas_hip_spmm_csr");
     }
     for (unsigned i = 0; i < n_gpu; ++i) pC->sync2cpu(i); // stream-ordered after GPU i's kernels
 }
@@ -119,7 +110,7 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     assert((pA->height) == (pC->height));
     assert((pB->width) == (pC->width));
     sblas_detail::require_col_major("SBLAS_SPMM_CSR_V2", pB, pC);
-    sblas_detail::require_f64_i32<IdxType, DataType>("SBLAS_SPMM_CSR_V2");
+    const int vt = sblas_rt::vtype_of<DataType>("SBLAS_SPMM_CSR_V2"), it = sblas_rt::itype_of<IdxType>("SBLAS_SPMM_CSR_V2");
     assert(pA->policy == segment && pB->policy == replicate && pC->policy == replicate);
     const int64_t M = pA->height, K = pA->width, N = pB->width;
     const size_t cnt = (size_t)M * (size_t)N;
@@ -137,7 +128,7 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     // in-place sum all-reduce, axpby.
     const char *merge_mode = getenv("SBLAS_MERGE");
     const bool use_allreduce = merge_mode && !strcmp(merge_mode, "allreduce");
-    std::vector<double *> ccopy(n_gpu, (double *)NULL), gather(n_gpu, (double *)NULL);
+    std::vector<DataType *> ccopy(n_gpu, (DataType *)NULL), gather(n_gpu, (DataType *)NULL);
     std::vector<void *> streams(n_gpu);
     std::vector<GPU_Timer *> timers(n_gpu);
     std::vector<int64_t> starts(n_gpu), nrows(n_gpu);
@@ -152,52 +143,49 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         streams[i] = sblas_rt::stream(i);
         const int64_t m_i = nrows[i];
         const int64_t nnz_i = (int64_t)pA->nnz_gpu[i];
-        const size_t ws_bytes = sblas_hip_spmm_csr_f64_i32_workspace(m_i, K, nnz_i, N);
+        const size_t ws_bytes = sblas_hip_spmm_csr_workspace(vt, it, m_i, K, nnz_i, N);
         void *ws = sblas_rt::workspace(i, ws_bytes);
         if (use_allreduce) {
             // zeroed partial-result buffer on the device (the reference uploads M*N zeros from the host);
             // A_i * B accumulated (alpha = beta = 1) at its row offset, ld = M
-            ccopy[i] = (double *)sblas_rt::workspace(i, cnt * sizeof(double), sblas_rt::WS_PARTIAL);
-            CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(double), (hipStream_t)streams[i]));
-            sblas_rt::must_sblas(
-                sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
-                                           (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
-                                           (const double *)pB->val_gpu[i], K, N, 1.0, 1.0,
-                                           ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
-                "sblas_hip_spmm_csr_f64_i32");
+            ccopy[i] = (DataType *)sblas_rt::workspace(i, cnt * sizeof(DataType), sblas_rt::WS_PARTIAL);
+            CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(DataType), (hipStream_t)streams[i]));
+            sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, streams[i], vt, it, m_i, K, nnz_i, pA->csrRowPtr_gpu[i],
+                                                    pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, N, 1.0, 1.0,
+                                                    ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
+                                 "sblas_hip_spmm_csr");
         } else {
             // packed m_i x N block, beta = 0: nothing to clear
-            ccopy[i] = (double *)sblas_rt::workspace(i, (size_t)m_i * (size_t)N * sizeof(double), sblas_rt::WS_PARTIAL);
-            gather[i] = (double *)sblas_rt::workspace(i, all_blocks * sizeof(double), sblas_rt::WS_GATHER);
-            sblas_rt::must_sblas(
-                sblas_hip_spmm_csr_f64_i32(-1, streams[i], m_i, K, nnz_i, (const int32_t *)pA->csrRowPtr_gpu[i],
-                                           (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
-                                           (const double *)pB->val_gpu[i], K, N, 1.0, 0.0, ccopy[i], m_i, ws, ws_bytes),
-                "sblas_hip_spmm_csr_f64_i32");
+            ccopy[i] = (DataType *)sblas_rt::workspace(i, (size_t)m_i * (size_t)N * sizeof(DataType), sblas_rt::WS_PARTIAL);
+            gather[i] = (DataType *)sblas_rt::workspace(i, all_blocks * sizeof(DataType), sblas_rt::WS_GATHER);
+            sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, streams[i], vt, it, m_i, K, nnz_i, pA->csrRowPtr_gpu[i],
+                                                    pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, N, 1.0, 0.0,
+                                                    ccopy[i], m_i, ws, ws_bytes),
+                                 "sblas_hip_spmm_csr");
         }
         timers[i] = new GPU_Timer((hipStream_t)streams[i]);
         timers[i]->start_timer();
     }
     if (use_allreduce) {
         // sum of the partial C over all GPUs (RCCL over xGMI; stream-ordered after each GPU's SpMM)
-        sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ccopy.data(), streams.data(), (int64_t)cnt),
-                             "sblas_hip_allreduce_sum_f64");
+        sblas_rt::must_sblas(sblas_hip_allreduce_sum(comm, vt, (void *const *)ccopy.data(), streams.data(), (int64_t)cnt),
+                             "sblas_hip_allreduce_sum");
     } else {
-        std::vector<double *> cptr(n_gpu);
-        for (unsigned i = 0; i < n_gpu; ++i) cptr[i] = (double *)pC->val_gpu[i];
-        sblas_rt::must_sblas(sblas_hip_merge_rowblocks_f64(comm, M, N, starts.data(), nrows.data(), ccopy.data(),
-                                                           gather.data(), (double)alpha, (double)beta, cptr.data(), M,
-                                                           streams.data()),
-                             "sblas_hip_merge_rowblocks_f64");
+        std::vector<void *> cptr(n_gpu);
+        for (unsigned i = 0; i < n_gpu; ++i) cptr[i] = pC->val_gpu[i];
+        sblas_rt::must_sblas(sblas_hip_merge_rowblocks(comm, vt, M, N, starts.data(), nrows.data(),
+                                                       (void *const *)ccopy.data(), (void *const *)gather.data(),
+                                                       (double)alpha, (double)beta, cptr.data(), M, streams.data()),
+                             "sblas_hip_merge_rowblocks");
     }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         timers[i]->stop_timer();
         if (use_allreduce) {
             // C = beta*C + alpha*Ccopy, same stream: no host round trip between merge and epilogue
-            sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], (int64_t)cnt, (double)alpha, ccopy[i],
-                                                     (double)beta, (double *)pC->val_gpu[i]),
-                                 "sblas_hip_axpby_f64");
+            sblas_rt::must_sblas(sblas_hip_axpby(-1, streams[i], vt, (int64_t)cnt, (double)alpha, ccopy[i], (double)beta,
+                                                 pC->val_gpu[i]),
+                                 "sblas_hip_axpby");
         }
     }
     sblas_rt::sync_all(n_gpu);

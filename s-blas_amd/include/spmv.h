@@ -41,7 +41,7 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
 {
     assert((pA->width == pB->length));
     assert((pA->height) == (pC->length));
-    sblas_detail::require_f64_i32<IdxType, DataType>("SBLAS_SPMV_CSR_V1");
+    const int vt = sblas_rt::vtype_of<DataType>("SBLAS_SPMV_CSR_V1"), it = sblas_rt::itype_of<IdxType>("SBLAS_SPMV_CSR_V1");
     assert(pA->policy == segment && pB->policy == replicate && pC->policy == replicate);
     const int64_t M = pA->height, K = pA->width;
 
@@ -54,7 +54,7 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
     // SBLAS_MERGE=allreduce for the reference's zero-filled y copy + all-reduce + axpby (spmv.h:60-138).
     const char *merge_mode = getenv("SBLAS_MERGE");
     const bool use_allreduce = merge_mode && !strcmp(merge_mode, "allreduce");
-    std::vector<double *> ycopy(n_gpu, (double *)NULL), gather(n_gpu, (double *)NULL);
+    std::vector<DataType *> ycopy(n_gpu, (DataType *)NULL), gather(n_gpu, (DataType *)NULL);
     std::vector<void *> streams(n_gpu);
     std::vector<GPU_Timer *> timers(n_gpu);
     std::vector<int64_t> starts(n_gpu), nrows(n_gpu);
@@ -69,40 +69,37 @@ void sblas_spmv_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseVector<IdxTy
         streams[i] = sblas_rt::stream(i);
         const int64_t m_i = nrows[i];
         if (use_allreduce) {
-            ycopy[i] = (double *)sblas_rt::workspace(i, (size_t)M * sizeof(double), sblas_rt::WS_PARTIAL);
-            CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(double), (hipStream_t)streams[i]));
+            ycopy[i] = (DataType *)sblas_rt::workspace(i, (size_t)M * sizeof(DataType), sblas_rt::WS_PARTIAL);
+            CUDA_SAFE_CALL(hipMemsetAsync(ycopy[i], 0, (size_t)M * sizeof(DataType), (hipStream_t)streams[i]));
         } else {
-            ycopy[i] = (double *)sblas_rt::workspace(i, (size_t)m_i * sizeof(double), sblas_rt::WS_PARTIAL);
-            gather[i] = (double *)sblas_rt::workspace(i, all_blocks * sizeof(double), sblas_rt::WS_GATHER);
+            ycopy[i] = (DataType *)sblas_rt::workspace(i, (size_t)m_i * sizeof(DataType), sblas_rt::WS_PARTIAL);
+            gather[i] = (DataType *)sblas_rt::workspace(i, all_blocks * sizeof(DataType), sblas_rt::WS_GATHER);
         }
         sblas_rt::must_sblas(
-            sblas_hip_spmv_csr_f64_i32(-1, streams[i], m_i, K, (int64_t)pA->nnz_gpu[i],
-                                       (const int32_t *)pA->csrRowPtr_gpu[i], (const int32_t *)pA->csrColIdx_gpu[i],
-                                       (const double *)pA->csrVal_gpu[i], (const double *)pB->val_gpu[i], 1.0,
-                                       use_allreduce ? 1.0 : 0.0,
-                                       use_allreduce ? ycopy[i] + (size_t)pA->starting_row_gpu[i] : ycopy[i]),
-            "sblas_hip_spmv_csr_f64_i32");
+            sblas_hip_spmv_csr(-1, streams[i], vt, it, m_i, K, (int64_t)pA->nnz_gpu[i], pA->csrRowPtr_gpu[i],
+                               pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], 1.0, use_allreduce ? 1.0 : 0.0,
+                               use_allreduce ? ycopy[i] + (size_t)pA->starting_row_gpu[i] : ycopy[i]),
+            "sblas_hip_spmv_csr");
         timers[i] = new GPU_Timer((hipStream_t)streams[i]);
         timers[i]->start_timer();
     }
     if (use_allreduce) {
-        sblas_rt::must_sblas(sblas_hip_allreduce_sum_f64(comm, ycopy.data(), streams.data(), M),
-                             "sblas_hip_allreduce_sum_f64");
+        sblas_rt::must_sblas(sblas_hip_allreduce_sum(comm, vt, (void *const *)ycopy.data(), streams.data(), M),
+                             "sblas_hip_allreduce_sum");
     } else {
-        std::vector<double *> yptr(n_gpu);
-        for (unsigned i = 0; i < n_gpu; ++i) yptr[i] = (double *)pC->val_gpu[i];
-        sblas_rt::must_sblas(sblas_hip_merge_rowblocks_f64(comm, M, 1, starts.data(), nrows.data(), ycopy.data(),
-                                                           gather.data(), (double)alpha, (double)beta, yptr.data(), M,
-                                                           streams.data()),
-                             "sblas_hip_merge_rowblocks_f64");
+        std::vector<void *> yptr(n_gpu);
+        for (unsigned i = 0; i < n_gpu; ++i) yptr[i] = pC->val_gpu[i];
+        sblas_rt::must_sblas(sblas_hip_merge_rowblocks(comm, vt, M, 1, starts.data(), nrows.data(),
+                                                       (void *const *)ycopy.data(), (void *const *)gather.data(),
+                                                       (double)alpha, (double)beta, yptr.data(), M, streams.data()),
+                             "sblas_hip_merge_rowblocks");
     }
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         timers[i]->stop_timer();
         if (use_allreduce)
-            sblas_rt::must_sblas(sblas_hip_axpby_f64(-1, streams[i], M, (double)alpha, ycopy[i], (double)beta,
-                                                     (double *)pC->val_gpu[i]),
-                                 "sblas_hip_axpby_f64");
+            sblas_rt::must_sblas(sblas_hip_axpby(-1, streams[i], vt, M, (double)alpha, ycopy[i], (double)beta, pC->val_gpu[i]),
+                                 "sblas_hip_axpby");
     }
     sblas_rt::sync_all(n_gpu);
     for (unsigned i = 0; i < n_gpu; ++i) {

@@ -148,6 +148,23 @@ inline void host_free(void *p)
     else free(p);
 }
 
+// Value / index type tags of the typed C-ABI entry points (the reference's getCudaDataType<T>() /
+// getCusparseIndexType<T>(), utility.h:302-316: float, double; int32_t, int64_t).  Anything else: print and exit.
+template <typename DataType> inline int vtype_of(const char *who)
+{
+    if (std::is_same<DataType, double>::value) return SBLAS_F64;
+    if (std::is_same<DataType, float>::value) return SBLAS_F32;
+    fprintf(stderr, "%s: values must be float or double\n", who);
+    exit(-1);
+}
+template <typename IdxType> inline int itype_of(const char *who)
+{
+    if (std::is_integral<IdxType>::value && std::is_signed<IdxType>::value && sizeof(IdxType) == 4) return SBLAS_I32;
+    if (std::is_integral<IdxType>::value && std::is_signed<IdxType>::value && sizeof(IdxType) == 8) return SBLAS_I64;
+    fprintf(stderr, "%s: indices must be 32- or 64-bit signed integers\n", who);
+    exit(-1);
+}
+
 } // namespace sblas_rt
 
 // ----------------------------------------------------------------------------------------------

@@ -25,6 +25,8 @@ EXPORTS = [
     "sblas_hip_merge_rowblocks_f64", "sblas_hip_merge_rowblocks_local_f64",
     "sblas_find_row_of_nnz", "sblas_partition_nnz", "sblas_partition_dense",
     "sblas_mm_read_info", "sblas_mm_read_csr", "sblas_host_fill_rand0to1",
+    "sblas_hip_spmm_csr_workspace", "sblas_hip_spmm_csr", "sblas_hip_spmv_csr", "sblas_hip_axpby",
+    "sblas_hip_allreduce_sum", "sblas_hip_merge_rowblocks", "sblas_partition_nnz_i64",
 ]
 
 
@@ -97,6 +99,21 @@ def lib():
     L.sblas_mm_read_csr.argtypes = [C.c_char_p, vp, vp, vp]
     L.sblas_host_fill_rand0to1.restype = C.c_int
     L.sblas_host_fill_rand0to1.argtypes = [vp, i64, C.c_uint]
+    L.sblas_hip_spmm_csr_workspace.restype = sz
+    L.sblas_hip_spmm_csr_workspace.argtypes = [C.c_int, C.c_int, i64, i64, i64, i64]
+    L.sblas_hip_spmm_csr.restype = C.c_int
+    L.sblas_hip_spmm_csr.argtypes = [C.c_int, vp, C.c_int, C.c_int, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64, vp, sz]
+    L.sblas_hip_spmv_csr.restype = C.c_int
+    L.sblas_hip_spmv_csr.argtypes = [C.c_int, vp, C.c_int, C.c_int, i64, i64, i64, vp, vp, vp, vp, f64, f64, vp]
+    L.sblas_hip_axpby.restype = C.c_int
+    L.sblas_hip_axpby.argtypes = [C.c_int, vp, C.c_int, i64, f64, vp, f64, vp]
+    L.sblas_hip_allreduce_sum.restype = C.c_int
+    L.sblas_hip_allreduce_sum.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp), i64]
+    L.sblas_hip_merge_rowblocks.restype = C.c_int
+    L.sblas_hip_merge_rowblocks.argtypes = [vp, C.c_int, i64, i64, C.POINTER(i64), C.POINTER(i64), C.POINTER(vp), C.POINTER(vp),
+                                            f64, f64, C.POINTER(vp), i64, C.POINTER(vp)]
+    L.sblas_partition_nnz_i64.restype = i64
+    L.sblas_partition_nnz_i64.argtypes = [vp, i64, i64, C.c_int, C.c_int] + [C.POINTER(i64)] * 4 + [vp]
     _lib = L
     return L
 
@@ -319,3 +336,92 @@ def panel_census(reset=True):
     out = (C.c_uint64 * 4)()
     check(lib().sblas_hip_debug_spmm_panel_stats(out, 1 if reset else 0), "sblas_hip_debug_spmm_panel_stats")
     return dict(windowed=int(out[0]), direct=int(out[1]), fallback=int(out[2]), mfma=int(out[3]))
+
+
+# ------------------------------------------------------------------------------------------
+# the other value / index types of the reference's templates (typed entry points; tags from the tensors' dtypes)
+# ------------------------------------------------------------------------------------------
+F64, F32, I32, I64 = 0, 1, 0, 1
+
+
+def _tags(val_dtype, idx_dtype):
+    import torch
+    vt = {torch.float64: F64, torch.float32: F32}.get(val_dtype)
+    it = {torch.int32: I32, torch.int64: I64}.get(idx_dtype)
+    if vt is None or it is None:
+        raise SblasError("values must be float32 / float64 and indices int32 / int64 tensors")
+    return vt, it
+
+
+def spmm_typed_workspace_bytes(val_dtype, idx_dtype, rows, cols, nnz, n):
+    vt, it = _tags(val_dtype, idx_dtype)
+    return int(lib().sblas_hip_spmm_csr_workspace(vt, it, rows, cols, nnz, n))
+
+
+def spmm_typed(rows, cols, rowptr, colidx, val, B, ldb, n, alpha, beta, Cmat, ldc, workspace, stream=None, c_offset=0):
+    """sblas_hip_spmm_csr: C = alpha*A*B + beta*C in the tensors' own value / index types (workspace: a uint8 tensor)."""
+    import torch
+    vt, it = _tags(val.dtype, rowptr.dtype)
+    nnz = int(colidx.numel())
+    rc = lib().sblas_hip_spmm_csr(
+        -1, _stream(stream), vt, it, rows, cols, nnz, _dev_ptr(rowptr, rowptr.dtype, "rowptr"),
+        _dev_ptr(colidx, rowptr.dtype, "colidx") if nnz else None, _dev_ptr(val, val.dtype, "val") if nnz else None,
+        _dev_ptr(B, val.dtype, "B") if cols else None, ldb, n, alpha, beta,
+        _dev_ptr(Cmat, val.dtype, "C") + Cmat.element_size() * c_offset, ldc,
+        _dev_ptr(workspace, torch.uint8, "workspace") if workspace is not None and workspace.numel() else None,
+        workspace.numel() if workspace is not None else 0)
+    check(rc, "sblas_hip_spmm_csr")
+
+
+def spmv_typed(rows, cols, rowptr, colidx, val, x, alpha, beta, y, stream=None, y_offset=0):
+    vt, it = _tags(val.dtype, rowptr.dtype)
+    nnz = int(colidx.numel())
+    rc = lib().sblas_hip_spmv_csr(
+        -1, _stream(stream), vt, it, rows, cols, nnz, _dev_ptr(rowptr, rowptr.dtype, "rowptr"),
+        _dev_ptr(colidx, rowptr.dtype, "colidx") if nnz else None, _dev_ptr(val, val.dtype, "val") if nnz else None,
+        _dev_ptr(x, val.dtype, "x"), alpha, beta, _dev_ptr(y, val.dtype, "y") + y.element_size() * y_offset)
+    check(rc, "sblas_hip_spmv_csr")
+
+
+def axpby_typed(n, alpha, x, beta, y, stream=None):
+    vt, _ = _tags(x.dtype, __import__("torch").int32)
+    check(lib().sblas_hip_axpby(-1, _stream(stream), vt, n, alpha, _dev_ptr(x, x.dtype, "x"), beta, _dev_ptr(y, x.dtype, "y")),
+          "sblas_hip_axpby")
+
+
+def _typed_ptr_array(tensors, dtype, what, allow_none=False):
+    vals = []
+    for t in tensors:
+        vals.append(None if t is None or (allow_none and t.numel() == 0) else _dev_ptr(t, dtype, what))
+    return (C.c_void_p * len(vals))(*vals)
+
+
+def allreduce_sum_typed(comm, bufs, streams, count):
+    vt, _ = _tags(bufs[0].dtype, __import__("torch").int32)
+    check(lib().sblas_hip_allreduce_sum(comm, vt, _typed_ptr_array(bufs, bufs[0].dtype, "buf"), _stream_array(streams), count),
+          "sblas_hip_allreduce_sum")
+
+
+def merge_rowblocks_typed(comm, M, N, starts, nrows, partial, gather, alpha, beta, Cs, ldc, streams):
+    dt = Cs[0].dtype
+    vt, _ = _tags(dt, __import__("torch").int32)
+    g = len(partial)
+    st = (C.c_int64 * g)(*[int(v) for v in starts])
+    nr = (C.c_int64 * g)(*[int(v) for v in nrows])
+    ga = _typed_ptr_array(gather, dt, "gather", allow_none=True) if gather is not None else None
+    check(lib().sblas_hip_merge_rowblocks(comm, vt, M, N, st, nr, _typed_ptr_array(partial, dt, "partial", allow_none=True), ga,
+                                          alpha, beta, _typed_ptr_array(Cs, dt, "C"), ldc, _stream_array(streams)),
+          "sblas_hip_merge_rowblocks")
+
+
+def partition_nnz_i64(rowptr, n_gpu, i_gpu):
+    """sblas_partition_nnz for 64-bit row pointers."""
+    rowptr = np.ascontiguousarray(rowptr, np.int64)
+    rows = len(rowptr) - 1
+    s, e, k, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    buf = np.zeros(rows + 2, np.int64)
+    num = lib().sblas_partition_nnz_i64(rowptr.ctypes.data, rows, int(rowptr[-1]), n_gpu, i_gpu, C.byref(s), C.byref(e),
+                                        C.byref(k), C.byref(f), buf.ctypes.data)
+    if num < 0:
+        raise SblasError("sblas_partition_nnz_i64 failed (%d)" % num)
+    return dict(start_row=s.value, stop_row=e.value, nnz=k.value, first_nnz=f.value, rowptr=buf[:num].copy())

@@ -292,3 +292,53 @@ def test_loader_parallel_tokenizer_matches_the_sequential_parse(sblas, tmp_path,
         monkeypatch.setenv("SBLAS_LOADER_THREADS", threads)
         with pytest.raises(sblas.SblasError):
             sblas.read_mtx(str(bad))
+
+
+def test_partition_nnz_i64_matches_the_int32_partition(sblas):
+    """CsrSparseMatrix<int64_t, T>::sync2gpu(segment) splits exactly as the int32 instantiation does (one template in
+    the reference, matrix.h:356-375)."""
+    from sblas_amd import synth
+    for seed, (rows, avg) in enumerate(((85, 6), (300, 3), (1000, 40))):
+        rp, ci, v = synth.random_csr(rows, rows, avg, seed=seed, empty_every=7, long_row=(rows // 3, 5 * avg * 4))
+        for g in (1, 2, 3, 4, 8):
+            for i in range(g):
+                a = sblas.partition_nnz(rp, g, i)
+                b = sblas.partition_nnz_i64(rp.astype(np.int64), g, i)
+                assert {k: a[k] for k in ("start_row", "stop_row", "nnz", "first_nnz")} == {k: b[k] for k in ("start_row", "stop_row", "nnz", "first_nnz")}
+                assert np.array_equal(a["rowptr"].astype(np.int64), b["rowptr"]) and b["rowptr"].dtype == np.int64
+
+
+def test_typed_oracle_agrees_with_the_fp64_int32_oracle(oracle):
+    """The typed restatements (float values, int64 indices) are the same loops: int64 indices give the fp64 results
+    bit for bit, fp32 values give the fp64 results to fp32 rounding."""
+    from sblas_amd import synth
+    rp, ci, v = synth.random_csr(120, 90, 8, seed=4, empty_every=9, long_row=(7, 200))
+    rng = np.random.default_rng(0)
+    n = 5
+    B, C0 = rng.standard_normal(90 * n), rng.standard_normal(120 * n)
+    x, y0 = rng.standard_normal(90), rng.standard_normal(120)
+    ref = oracle.spmm(120, 90, n, rp, ci, v, B, C0.copy(), 1.5, -0.5)
+    refv = oracle.spmv(120, rp, ci, v, x, y0.copy(), 1.5, -0.5)
+    rp8, ci8 = rp.astype(np.int64), ci.astype(np.int64)
+    assert np.array_equal(oracle.spmm_typed(120, 90, n, rp8, ci8, v, B, C0.copy(), 1.5, -0.5), ref)
+    assert np.array_equal(oracle.spmv_typed(120, rp8, ci8, v, x, y0.copy(), 1.5, -0.5), refv)
+    f = np.float32
+    for r, c in ((rp, ci), (rp8, ci8)):
+        got = oracle.spmm_typed(120, 90, n, r, c, v.astype(f), B.astype(f), C0.astype(f), 1.5, -0.5)
+        assert got.dtype == f and np.allclose(got, ref, rtol=1e-4, atol=1e-4)
+        gotv = oracle.spmv_typed(120, r, c, v.astype(f), x.astype(f), y0.astype(f), 1.5, -0.5)
+        assert gotv.dtype == f and np.allclose(gotv, refv, rtol=1e-4, atol=1e-4)
+
+
+def test_typed_entry_points_validate_without_a_gpu(sblas):
+    L = sblas.lib()
+    one = (C.c_double * 4)()
+    assert L.sblas_hip_spmm_csr(-1, None, 7, 0, 4, 4, 3, one, one, one, one, 4, 2, 1.0, 0.0, one, 4, None, 0) == 1      # unknown value type
+    assert L.sblas_hip_spmm_csr(-1, None, 1, 2, 4, 4, 3, one, one, one, one, 4, 2, 1.0, 0.0, one, 4, None, 0) == 1      # unknown index type
+    assert L.sblas_hip_spmm_csr(-1, None, 1, 1, 4, 4, 3, one, one, one, one, 4, 2, 1.0, 0.0, one, 4, None, 0) == 3      # no workspace
+    assert L.sblas_hip_spmm_csr(-1, None, 1, 0, 0, 4, 0, one, None, None, one, 4, 2, 1.0, 0.0, one, 4, None, 0) == 0    # no rows
+    assert L.sblas_hip_spmv_csr(-1, None, 1, 1, 4, 4, 3, one, None, one, one, 1.0, 0.0, one) == 1                      # nnz > 0 without colidx
+    assert L.sblas_hip_axpby(-1, None, 5, 4, 1.0, one, 1.0, one) == 1
+    assert L.sblas_hip_spmm_csr_workspace(1, 0, 10, 100, 5, 65) == 100 * 128 * 4      # fp32: cols x (n rounded up to 64)
+    assert L.sblas_hip_spmm_csr_workspace(0, 1, 10, 100, 5, 64) == 100 * 64 * 8
+    assert L.sblas_hip_spmm_csr_workspace(0, 0, 10, 100, 5, 64) == L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64)
