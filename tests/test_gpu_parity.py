@@ -1253,6 +1253,21 @@ def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
             os.environ.pop("SBLAS_SPMM_MAX_BT_BYTES", None)
             sblas.reload_env()
         assert close(got, ref), (n, width, np.abs(got - ref).max())
+    # the same walk with the range staging of a row block: every chunk stages the block's column range again
+    sub = (rp[200:451] - rp[200]).astype(np.int32)
+    As = Dev(torch, dev, sub, ci[rp[200]:rp[450]], v[rp[200]:rp[450]], K)
+    Cs = rng.standard_normal(250 * n)
+    want = oracle.spmm(250, K, n, *As.h, B, Cs.copy(), 1.5, -1.0)
+    os.environ["SBLAS_SPMM_MAX_BT_BYTES"] = str(8 * 701 * 64)
+    os.environ["SBLAS_STAGE_RANGE"] = "1"
+    sblas.reload_env()
+    try:
+        got = gpu_spmm(sblas, torch, dev, As, B, K, n, 1.5, -1.0, Cs, 250)
+    finally:
+        os.environ.pop("SBLAS_SPMM_MAX_BT_BYTES", None)
+        os.environ.pop("SBLAS_STAGE_RANGE", None)
+        sblas.reload_env()
+    assert close(got, want)
 
 
 @pytest.mark.parametrize("variant", ["auto", "dpp"])
