@@ -191,6 +191,8 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
     double *Bt = static_cast<double *>(workspace);
     const int64_t w = spmm_chunk_cols(cols, n);
+    int range_epoch = 0;      // range staging: the first chunk's column range and panel verdicts serve the later chunks
+    int64_t range_ldbt = 0;
     for (int64_t j0 = 0; j0 < n; j0 += w) { // one pass unless Bt would exceed the 32-bit offset window
         const int64_t nj = (n - j0 < w) ? n - j0 : w;
         const int64_t ldbt = chunk_ldbt(cols, n, nj);
@@ -207,9 +209,12 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
             const bool direct_only = spmm_variant() == sblas::SPMM_VARIANT_DIRECT_DPP ||
                                      spmm_variant() == sblas::SPMM_VARIANT_DIRECT_ROWS ||
                                      spmm_variant() == sblas::SPMM_VARIANT_DIRECT_MERGE;
+            pre_epoch = (!direct_only && ldbt == range_ldbt) ? range_epoch : 0;
             if (sblas::launch_stage_range((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, (int)rows, nnz,
                                           rowptr, colidx, spmm_variant(), direct_only ? 0 : 1, &pre_epoch) != hipSuccess)
                 return SBLAS_E_HIP;
+            range_epoch = pre_epoch;
+            range_ldbt = ldbt;
         } else if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
             spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
             ldbt_ok(ldbt, nj)) {

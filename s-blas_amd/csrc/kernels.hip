@@ -1756,8 +1756,11 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
 {
     const Tail t = tail_of(Bt, cols, ldbt, rows);
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 4095) / 4096, TAIL_PARTS));
-    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
-    if (classify) {
+    // *epoch_out != 0 on entry: a later column chunk of the same call (same A, same ldbt, same workspace): the column
+    // range and the panel verdicts in the tail still stand, only B's next columns need staging
+    const bool again = *epoch_out != 0;
+    const int epoch = again ? *epoch_out : g_epoch.fetch_add(1, std::memory_order_relaxed);
+    if (!again && classify) {
         int info_rows = 0, g = 2;
         gen6_plan(rows, info_rows, g);
         const int np = (rows + info_rows - 1) / info_rows;
@@ -1765,13 +1768,13 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
                            nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f,
                            mfma_min_fill(variant, info_rows, ldbt), (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr,
                            t.info, t.cls, epoch);
-    } else {
+    } else if (!again) {
         hipLaunchKernelGGL(colrange_kernel, dim3(nparts), dim3(256), 0, s, nnz, colidx, t.parts);
     }
     const int64_t tiles = ((cols + 1 + STAGE_K - 1) / STAGE_K) * ((ldbt + 63) / 64);
     hipLaunchKernelGGL(stage_range_kernel, dim3((unsigned)std::min<int64_t>(tiles, 2048)), dim3(256), 0, s, cols, n, B,
                        ldb, Bt, ldbt, t.hdr, t.parts, nparts, epoch);
-    *epoch_out = classify ? epoch : 0;
+    *epoch_out = (classify || again) ? epoch : 0;
     return hipGetLastError();
 }
 
