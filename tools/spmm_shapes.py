@@ -55,7 +55,7 @@ def set_variant(spec):
     S.reload_env()
 
 
-KEEP = set()
+KEEP = {k for k in os.environ if k.startswith("SBLAS_")}     # switches set by the caller stay for every variant
 
 
 def main():
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--variants", default="auto")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--beta", type=float, default=1.0, help="beta of the timed steps")
     ap.add_argument("--block", default="", help="i/g: time row block i of g (split by nonzeros, as method 2 does)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -109,7 +110,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.steps):
-                    S.spmm(rows, K, rowptr, colidx, val, B, K, n, 1.0, 1.0, C, rows, ws)
+                    S.spmm(rows, K, rowptr, colidx, val, B, K, n, 1.0, args.beta, C, rows, ws)
                 e1.record()
                 torch.cuda.synchronize()
                 times[vs].append(e0.elapsed_time(e1) / args.steps)
