@@ -351,16 +351,17 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                    (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
-    // Do neighbouring rows list the same columns (the rows of one mesh node in a multi-dof FEM matrix)?  Rows 0/1, 1/2
-    // and 2/3 of the panel are compared entry by entry; the row-merging direct kernel pays only where they do.  The
-    // three answers also say where a group of three such rows STARTS (a method-2 row block begins anywhere): the row
-    // index of a group start, modulo 3, rides in the class word and the merging kernel lines its waves up with it.
+    // Do THREE neighbouring rows list the same columns (the rows of one mesh node in a 3-dof FEM matrix; six dofs are two
+    // such groups)?  Neighbouring rows of the panel's head are compared entry by entry until two consecutive pairs
+    // agree: rows k, k+1, k+2 are a group and (row index of k) mod 3 is where groups start -- a method-2 row block begins
+    // anywhere -- which rides in the class word; the row-merging kernel lines its waves up with it.  Pairs that agree
+    // without a third row (two dofs per node) do not count: that kernel would only run its slower unmerged path.
     bool shared = false;
     int phase = 0;
     if (sane && !window_ok && merge_probe) {
         const int r0 = p * panel_rows;
-        bool eqk[3] = {false, false, false};
-        for (int k = 0; k < 3; ++k) {
+        bool prev = false;
+        for (int k = 0; k < 4 && !shared; ++k) {
             if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
             const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
             bool eq = b - a == c2 - b && b > a;
@@ -369,12 +370,12 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                 for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
                 eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
             }
-            eqk[k] = eq;
-            if (k == 1 && eqk[0] && eqk[1]) break; // rows 0..2 are one group
+            if (eq && prev) { // rows k-1, k, k+1
+                shared = true;
+                phase = (r0 + k - 1) % 3;
+            }
+            prev = eq;
         }
-        shared = eqk[0] || eqk[1] || eqk[2];
-        const int t = (eqk[0] && eqk[1]) ? 0 : (!eqk[0] && eqk[1] && eqk[2]) ? 1 : (eqk[0] && !eqk[1] && eqk[2]) ? 2 : 0;
-        phase = (r0 + t) % 3;
     }
     if (lane == 0) {
         info[p] = last >= first ? make_int2(first, last) : make_int2(1, 0);

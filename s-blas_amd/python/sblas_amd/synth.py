@@ -140,22 +140,23 @@ def block_structured(rows, nnz_per_row=399, half_band=2000, block_rows=16, block
     return rowptr.astype(np.int32), colidx, val
 
 
-def queen_like_grid(rows, seed=SEED, half_band=50000, keep=0.93):
+def queen_like_grid(rows, seed=SEED, half_band=50000, keep=0.93, dofs=3):
     """Queen_4147-like rows with the locality a 3-D FEM numbering has (queen_like() scatters its 40 offsets uniformly,
     which no mesh ordering does): nodes of a structured nx x ny x nz grid numbered x-fastest, 3 dofs per node, every
     node coupled to its 27 grid neighbours (each kept with probability `keep`, the diagonal always), i.e. up to
     27 x 3 = 81 columns per row in nine runs of nine consecutive columns; the plane size nx*ny is chosen so that
     the farthest neighbour sits `half_band` rows away (3 * (nx*ny + nx + 1) ~ half_band).  `rows` is rounded down
-    to whole nodes.  Columns ascending, duplicate-free, values U[-1, 1)."""
+    to whole nodes.  Columns ascending, duplicate-free, values U[-1, 1).  `dofs`: unknowns per node (3 = Queen_4147's;
+    2 and 6 exercise the row-merging kernel's group detection)."""
     rng = np.random.Generator(np.random.MT19937(seed))
-    nodes = max(rows // 3, 8)
-    plane = max(4, min(half_band // 3, nodes // 3))
+    nodes = max(rows // dofs, 8)
+    plane = max(4, min(half_band // dofs, nodes // 3))
     nx = max(2, int(np.sqrt(plane)))
     ny = max(2, plane // nx)
     plane = nx * ny
     nz = max(1, (nodes + plane - 1) // plane)
     nodes = min(nodes, plane * nz)
-    rows = nodes * 3
+    rows = nodes * dofs
     n = np.arange(nodes, dtype=np.int64)
     x, y, z = n % nx, (n // nx) % ny, n // plane
     cols_parts, cnt = [], np.zeros(nodes, np.int64)
@@ -173,18 +174,18 @@ def queen_like_grid(rows, seed=SEED, half_band=50000, keep=0.93):
     per_node = ok.sum(1)
     # rows of a node share its column set: 3 dofs x (neighbours x 3 dofs)
     rowptr = np.zeros(rows + 1, np.int64)
-    np.cumsum(np.repeat(per_node * 3, 3), out=rowptr[1:])
+    np.cumsum(np.repeat(per_node * dofs, dofs), out=rowptr[1:])
     colidx = np.empty(int(rowptr[-1]), np.int32)
     flat_nb = nb[ok]                                              # neighbours in ascending order per node (offs is sorted)
     node_start = np.zeros(nodes + 1, np.int64)
     np.cumsum(per_node, out=node_start[1:])
-    c3 = (flat_nb[:, None] * 3 + np.arange(3)[None, :]).reshape(-1)   # columns of one row of each node, node after node
+    c3 = (flat_nb[:, None] * dofs + np.arange(dofs)[None, :]).reshape(-1)   # columns of one row of each node, node after node
     # scatter: row 3n+d gets the 3*per_node[n] columns of node n
-    starts = rowptr[:-1].reshape(nodes, 3)
-    lens = per_node * 3
-    src_start = node_start[:-1] * 3
+    starts = rowptr[:-1].reshape(nodes, dofs)
+    lens = per_node * dofs
+    src_start = node_start[:-1] * dofs
     idx_in = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(src_start, lens)
-    for d in range(3):
+    for d in range(dofs):
         colidx[np.repeat(starts[:, d], lens) + idx_in] = c3
     val = rng.random(colidx.size) * 2.0 - 1.0
     return rowptr.astype(np.int32), colidx, val

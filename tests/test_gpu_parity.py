@@ -1227,6 +1227,35 @@ def test_spmm_row_merging_kernel_on_row_blocks_at_any_offset(env, variant_env, v
         assert close(got, oracle.spmm(m, K, n, *A.h, B, C0.copy(), 0.5, 2.0))
 
 
+@pytest.mark.parametrize("dofs", [2, 3, 6])
+def test_spmm_row_merging_kernel_only_where_three_rows_share_a_pattern(env, dofs):
+    """Nodes of 3 (and 6 = 2 x 3) unknowns give groups of three rows with one column pattern: the row-merging kernel
+    owns the call's direct panels.  Nodes of 2 give pairs only: that kernel would run its slower unmerged path, so the
+    call stays with the row-per-wave kernel.  Read back from the workspace header (TAIL_DIRECT_EPOCH = 2,
+    TAIL_MERGE_EPOCH = 6 in kernels.h); the result is checked either way, for a whole matrix and for an odd row block."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rp, ci, v = synth.queen_like_grid(9000, half_band=1500, dofs=dofs)
+    K = len(rp) - 1
+    n = 128
+    rng = np.random.default_rng(dofs)
+    for a, b in ((0, K), (1001, 4500)):
+        m = b - a
+        sub = (rp[a:b + 1] - rp[a]).astype(np.int32)
+        A = Dev(torch, dev, sub, ci[rp[a]:rp[b]], v[rp[a]:rp[b]], K)
+        Bh, C0 = rng.standard_normal(K * n), rng.standard_normal(m * n)
+        B, C = torch.from_numpy(Bh).to(dev), torch.from_numpy(C0.copy()).to(dev)
+        ws = torch.zeros(sblas.spmm_workspace_bytes(m, K, len(A.h[1]), n) // 8, dtype=torch.float64, device=dev)
+        sblas.panel_census()
+        sblas.spmm(m, K, A.rowptr, A.colidx, A.val, B, K, n, 2.0, -1.0, C, m, ws)
+        torch.cuda.synchronize()
+        assert sblas.panel_census()["direct"] > 0
+        hdr = ws[(K + 1) * 128:].view(torch.int32)[:16].cpu().numpy()
+        assert hdr[2] != 0
+        assert (hdr[6] == hdr[2]) == (dofs != 2), (dofs, a, hdr[:8])
+        assert close(C.cpu().numpy(), oracle.spmm(m, K, n, *A.h, Bh, C0.copy(), 2.0, -1.0))
+
+
 @pytest.mark.parametrize("n", [64, 200, 256, 300])
 def test_spmm_column_chunking_when_bt_exceeds_the_offset_window(env, n):
     """BASELINE config 5 shape problem (Queen_4147, N = 256: the row-major copy of B is 8.5 GB) in miniature: with the
