@@ -351,17 +351,19 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                    (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
-    // Do THREE neighbouring rows list the same columns (the rows of one mesh node in a 3-dof FEM matrix; six dofs are two
-    // such groups)?  Neighbouring rows of the panel's head are compared entry by entry until two consecutive pairs
-    // agree: rows k, k+1, k+2 are a group and (row index of k) mod 3 is where groups start -- a method-2 row block begins
-    // anywhere -- which rides in the class word; the row-merging kernel lines its waves up with it.  Pairs that agree
-    // without a third row (two dofs per node) do not count: that kernel would only run its slower unmerged path.
+    // Do the rows come in groups that list the same columns (the unknowns of one mesh node in a multi-dof FEM matrix),
+    // and is the group length a multiple of three (3-dof nodes; six dofs are two groups of three)?  Neighbouring rows
+    // at the panel's head are compared entry by entry: the first pair that differs ends the (possibly cut) group the
+    // panel starts in, the pairs that agree behind it measure the next group.  Only lengths 3, 6, 9 feed the
+    // row-merging kernel three rows at a time throughout (groups of four merge half of their triples and lose to the
+    // other kernels; pairs do not merge at all); (row index of a group start) mod 3 rides in the class word, so that
+    // the merging kernel lines its waves up with the groups -- a method-2 row block begins anywhere.
     bool shared = false;
     int phase = 0;
     if (sane && !window_ok && merge_probe) {
         const int r0 = p * panel_rows;
-        bool prev = false;
-        for (int k = 0; k < 4 && !shared; ++k) {
+        int start = -1, len = 0; // first row of the measured group (relative to r0), rows counted so far
+        for (int k = 0; k < 12; ++k) {
             if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
             const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
             bool eq = b - a == c2 - b && b > a;
@@ -370,11 +372,18 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                 for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
                 eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
             }
-            if (eq && prev) { // rows k-1, k, k+1
-                shared = true;
-                phase = (r0 + k - 1) % 3;
+            if (start < 0) {
+                if (!eq) start = k + 1, len = 1; // row k+1 opens a group
+            } else if (eq) {
+                ++len;
+            } else {
+                break; // the group is rows start .. start + len - 1
             }
-            prev = eq;
+            if (len > 9) break;
+        }
+        if (start >= 0 && len >= 3 && len <= 9 && len % 3 == 0) {
+            shared = true;
+            phase = (r0 + start) % 3;
         }
     }
     if (lane == 0) {
@@ -460,27 +469,40 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
     __shared__ int counts[4];
     if (threadIdx.x < 4) counts[threadIdx.x] = 0;
     __syncthreads();
-    int mine = 0, all = 0;
+    int mine = 0, all = 0, beyond = 0, groups = 0;
     for (int p = threadIdx.x; p < npanels; p += 1024) {
         const int2 sp = info[p];
-        const int c = cls[p] & PANEL_CLASS_MASK;
+        const int w = cls[p], c = w & PANEL_CLASS_MASK;
         if (sp.x <= sp.y) {
             ++all;
             mine += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
+            if (c == PANEL_DIRECT || c == PANEL_MFMA_D) {
+                ++beyond;
+                groups += (w & PANEL_SHARED_ROWS) != 0;
+            }
         }
     }
     atomicAdd(&counts[0], mine);
     atomicAdd(&counts[1], all);
+    atomicAdd(&counts[2], beyond);
+    atomicAdd(&counts[3], groups);
     __syncthreads();
     const bool demote = !mfma_forced && counts[0] > 0 && 4 * counts[0] < 3 * counts[1];
+    // Panels whose rows merge three at a time are better off with the row-merging kernel than with the matrix cores
+    // (6-dof grid rows, N = 256: 1.86 ms against 2.81 ms): where half of the panels outside the LDS-tiled kernel's
+    // reach show such groups, the matrix-core kernel's share of them goes to the direct path.
+    const bool to_merge = !mfma_forced && counts[2] > 0 && 2 * counts[3] >= counts[2];
+    __syncthreads();
+    if (threadIdx.x < 4) counts[threadIdx.x] = 0;
+    __syncthreads();
     // the direct kernel's panels after the vote: do their rows share column patterns?  (half of them: the row-merging
     // kernel takes all of the call's direct panels, otherwise the row-per-wave kernel does)
-    int direct = 0, shared = 0;
+    int direct = 0, shared = 0, left = 0;
     bool any_direct = false;
     for (int p = threadIdx.x; p < npanels; p += 1024) {
         int c = cls[p] & PANEL_CLASS_MASK;
         const int flag = cls[p] & ~PANEL_CLASS_MASK; // shared-rows flag and group phase stay
-        if (demote) {
+        if (demote || (to_merge && c == PANEL_MFMA_D)) {
             if (c == PANEL_MFMA_W) c = PANEL_WINDOW;
             if (c == PANEL_MFMA_D) {
                 c = PANEL_DIRECT;
@@ -488,6 +510,7 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
             }
             cls[p] = c | flag;
         }
+        left += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
         const int2 sp = info[p];
         if (c == PANEL_DIRECT && sp.x <= sp.y) {
             ++direct;
@@ -496,10 +519,11 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
     }
     atomicAdd(&counts[2], direct);
     atomicAdd(&counts[3], shared);
+    atomicAdd(&counts[0], left);
     if (any_direct) tail[TAIL_DIRECT_EPOCH] = epoch; // (every writer stores the same value)
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (demote) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel any more
+        if (counts[0] == 0) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel (any more)
         if (counts[2] > 0 && 2 * counts[3] >= counts[2]) tail[TAIL_MERGE_EPOCH] = epoch;
     }
 }

@@ -5,7 +5,7 @@ one process, median of the rounds), with the panel census and an oracle check of
     nd24k[:scale]              banded uniform stand-in (bench shape)
     blocks[:rows[:fill]]       nd24k-like rows in dense 16 x 4 sub-blocks (synth.block_structured)
     queen[:rows]               Queen-like, 40 scattered offsets (synth.queen_like)
-    qgrid[:rows]               Queen-like on a structured 3-D grid (synth.queen_like_grid)
+    qgrid[:rows[:dofs]]        Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node unless given
     powerlaw[:rows]            webbase-like row lengths (synth.powerlaw)
 Environment switches of the library can be set per variant as name=ENV1=val1+ENV2=val2."""
 import argparse, os, sys, time
@@ -29,7 +29,7 @@ def make(shape):
         rows = int(parts[1]) if len(parts) > 1 else 300000
         rp, ci, v = synth.queen_like(rows)
     elif kind == "qgrid":
-        rp, ci, v = synth.queen_like_grid(int(parts[1]) if len(parts) > 1 else 300000)
+        rp, ci, v = synth.queen_like_grid(int(parts[1]) if len(parts) > 1 else 300000, dofs=int(parts[2]) if len(parts) > 2 else 3)
         rows = len(rp) - 1
     elif kind == "banded":
         rows = int(parts[1])
