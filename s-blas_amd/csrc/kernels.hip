@@ -608,10 +608,6 @@ __device__ __forceinline__ sblas_rsrc_t make_rsrc(const void *p, unsigned stride
                    "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
                    "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
 
-// steps come in pairs; a pair whose second step lies past the end runs it on masked slots (value 0, zero row)
-#define SBLAS_QPAIR(K0, K1)                                                                                          \
-    if (npairs > (K0 / 2)) {                                                                                         \
-
 __device__ __forceinline__ void dma_rows_scalar(unsigned lds_addr, unsigned voff, const char *base)
 {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(base)
@@ -1747,7 +1743,7 @@ size_t workspace_tail_bytes(int64_t rows)
     return (TAIL_HDR * sizeof(int) + TAIL_PARTS * sizeof(int2) + panels * (sizeof(int2) + sizeof(int)) + 31) / 16 * 16; // whole 16-byte units
 }
 // block fill from which a panel goes to the matrix cores (fp64 MFMA and fp64 vector FMA have the same peak on gfx950,
-// so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/mfma_fill_sweep.py
+// so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/spmm_shapes.py blocks:ROWS:FILL
 static float mfma_min_fill(int variant, int panel_rows, int64_t ldbt)
 {
     if (panel_rows > 16 * MFMA_MAX_WAVES) return 2.0f; // the matrix-core kernel runs one wave per 16 rows of a panel
