@@ -17,5 +17,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcspmv_$c -- python3 $R/bench.py --op spmv --steps 5 --warmup 1 > /dev/null 2> $OUT/pmcspmv_$c.err
   echo "spmv $c rc=$?"
 done
+# the traffic figures the bench line quotes must come from THESE sources: summarise the counter passes into profiles/ of this
+# copy first (the caller runs collect_profiles.py again on the merged gpurun_out/ to commit them)
+cd $R && python tools/collect_profiles.py r02 > $OUT/collect.log 2>&1
 cd $R && python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"; cat $OUT/bench_default.json
 python bench.py --op spmv --steps 100 > $OUT/bench_spmv.json 2>/dev/null; cat $OUT/bench_spmv.json
