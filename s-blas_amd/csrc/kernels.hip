@@ -343,12 +343,30 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                     else in_range = false; // an unsorted row's entry outside [first, last]: not a candidate
                 }
             }
-            int nblk = 0;
-            for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) nblk += __popc(bitmap[w]);
+            int nblk = 0, nchunk = 0; // blocks, and 64-column chunks (16 blocks) that hold one
+            for (int w = lane; w < MFMA_BITMAP_WORDS; w += WAVE) {
+                const unsigned bits = bitmap[w];
+                nblk += __popc(bits);
+                nchunk += ((bits & 0xffffu) != 0u) + ((bits >> 16) != 0u);
+            }
 #pragma unroll
-            for (int m = 32; m > 0; m >>= 1) nblk += __shfl_xor(nblk, m, WAVE);
-            mfma = __builtin_amdgcn_ballot_w64(!in_range) == 0ull &&
-                   (float)(e1 - e0) >= mfma_min_fill * (float)(r1 - r0) * 4.0f * (float)nblk;
+            for (int m = 32; m > 0; m >>= 1) {
+                nblk += __shfl_xor(nblk, m, WAVE);
+                nchunk += __shfl_xor(nchunk, m, WAVE);
+            }
+            // Panels the LDS-tiled kernel cannot take compete with the (slower) row-per-wave kernel, and the matrix-core
+            // kernel pays a fixed price per 64-column chunk it visits.  Measured on such panels at N = 256: blocks
+            // scattered one to a chunk (80 per row over a +-50 000 band) lose at any fill (50 %: 1.90 ms against 1.33
+            // ms); with 4-5 blocks per chunk (grid-structured rows) 32 % fill loses by 8 %, 48 % wins by 23 %.  So:
+            // at least two blocks per visited chunk, and from three on 0.84 of the fill threshold is enough.
+            float need = mfma_min_fill;
+            bool dense_chunks = true;
+            if (!window_ok && mfma_min_fill > 0.0f) {
+                dense_chunks = nblk >= 2 * nchunk;
+                if (nblk >= 3 * nchunk) need *= 0.84f;
+            }
+            mfma = dense_chunks && __builtin_amdgcn_ballot_w64(!in_range) == 0ull &&
+                   (float)(e1 - e0) >= need * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
     // Do the rows come in groups that list the same columns (the unknowns of one mesh node in a multi-dof FEM matrix),

@@ -4,6 +4,7 @@ one process, median of the rounds), with the panel census and an oracle check of
   python tools/spmm_shapes.py SHAPE[:ARG[:ARG]] ... [--n N] [--variants auto,nomfma,dpp] [--rounds R] [--steps K]
     nd24k[:scale]              banded uniform stand-in (bench shape)
     blocks[:rows[:fill]]       nd24k-like rows in dense 16 x 4 sub-blocks (synth.block_structured)
+    blocksw[:rows[:fill]]      16 x 4 sub-blocks, 80 per row, over a +-50 000 band (direct-class panels)
     queen[:rows]               Queen-like, 40 scattered offsets (synth.queen_like)
     qgrid[:rows[:dofs]]        Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node unless given
     powerlaw[:rows]            webbase-like row lengths (synth.powerlaw)
@@ -25,6 +26,9 @@ def make(shape):
     elif kind == "blocks":
         rows = int(parts[1]) if len(parts) > 1 else 72000
         rp, ci, v = synth.block_structured(rows, fill=float(parts[2]) if len(parts) > 2 else 0.6)
+    elif kind == "blocksw":   # the same sub-blocks scattered over a +-50 000 band: no panel fits the LDS-tiled kernel
+        rows = int(parts[1]) if len(parts) > 1 else 300000
+        rp, ci, v = synth.block_structured(rows, nnz_per_row=80, half_band=50000, fill=float(parts[2]) if len(parts) > 2 else 0.6)
     elif kind == "queen":
         rows = int(parts[1]) if len(parts) > 1 else 300000
         rp, ci, v = synth.queen_like(rows)
