@@ -830,7 +830,8 @@ def main():
             if store is not None:
                 store.set("sblas_extras_done", "1")
         elif store is not None:
-            store.wait(["sblas_extras_done"])
+            import datetime   # (explicit: the store's own default may be shorter than the child's limit)
+            store.wait(["sblas_extras_done"], datetime.timedelta(seconds=args.extras_timeout + 180.0))
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(rows, cols, n, rp, ci, v, Bh, args.cpu_seconds)
