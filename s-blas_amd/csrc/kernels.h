@@ -56,6 +56,7 @@ struct Options {
     int stage_range = -1;                 // SBLAS_STAGE_RANGE: stage only the rows of B a row block refers to (-1: when the saved staging traffic outweighs the column-range pass)
     int direct_merge = 1;                 // SBLAS_DIRECT_MERGE: 128-column direct panels through the row-merging kernel
     double rows8_min_avg = 256.0;         // SBLAS_ROWS8_MIN_AVG
+    float window_density = 0.42f;         // SBLAS_WINDOW_DENSITY: the LDS-tiled kernel's bar, in nonzeros per spanned column of a 16-row slice of a panel
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
     int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE
     float mfma_min_fill = -1.0f;          // SBLAS_MFMA_MIN_FILL: block fill from which a panel takes the MFMA kernel (< 0: built-in rule)

@@ -304,14 +304,54 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         mlen = max(mlen, __shfl_xor(mlen, m, WAVE));
     }
     const bool sane = last >= first && first >= 0 && last < cols; // (first / last of sorted rows; the kernels re-check)
-    const bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1);
+    bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1);
+    // Do the rows come in groups that list the same columns (the unknowns of one mesh node in a multi-dof FEM matrix),
+    // and is the group length a multiple of three (3-dof nodes; six dofs are two groups of three)?  Neighbouring rows
+    // at the panel's head are compared entry by entry: the first pair that differs ends the (possibly cut) group the
+    // panel starts in, the pairs that agree behind it measure the next group.  Only lengths 3, 6, 9 feed the
+    // row-merging kernel three rows at a time throughout (groups of four merge half of their triples and lose to the
+    // other kernels; pairs do not merge at all); (row index of a group start) mod 3 rides in the class word, so that
+    // the merging kernel lines its waves up with the groups -- a method-2 row block begins anywhere.
+    // Probed where the row-merging kernel is a choice (128+ staged columns): on the panels the LDS-tiled kernel cannot
+    // take, and on those it would take only under the lowered bar -- grid-structured rows of three unknowns per node,
+    // band +-1000, N = 256: 1.32 ms merged against 2.32 ms through LDS -- which then go to the direct path.
+    bool shared = false;
+    int phase = 0;
+    const bool strong = window_ok && (float)nnz >= (float)panel_rows / 16.0f * (float)(last - first + 1);
+    if (sane && !strong && merge_probe) {
+        const int r0 = p * panel_rows;
+        int start = -1, len = 0; // first row of the measured group (relative to r0), rows counted so far
+        for (int k = 0; k < 12; ++k) {
+            if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
+            const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
+            bool eq = b - a == c2 - b && b > a;
+            if (eq) {
+                bool differ = false;
+                for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
+                eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
+            }
+            if (start < 0) {
+                if (!eq) start = k + 1, len = 1; // row k+1 opens a group
+            } else if (eq) {
+                ++len;
+            } else {
+                break; // the group is rows start .. start + len - 1
+            }
+            if (len > 9) break;
+        }
+        if (start >= 0 && len >= 3 && len <= 9 && len % 3 == 0) {
+            shared = true;
+            phase = (r0 + start) % 3;
+            window_ok = false;
+        }
+    }
     // Matrix cores?  The fill of the 16 x 4 blocks a 16-row group touches, sampled on the panel's first 16 rows.  A
     // cheap filter first, on the panel's first row alone: the block fill cannot exceed a row's own fill of the 4-column
     // blocks it touches (entries / (4 x distinct blocks)), and that takes one pass over one row.
-    bool mfma = false;
-    if (sane && mfma_min_fill <= 1.0f && last < 0x7fff0000) { // (the kernel's end-of-row sentinel is 0x7fffffff)
+    // the longest of the panel's first 16 rows (the first row itself may be empty): its length and the number of
+    // distinct 4-column blocks it touches, one pass over one row
+    auto head_row = [&](int &len_out, int &runs_out) {
         const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
-        // (the longest of the first 16 rows: the first row itself may be empty)
         int slen = 0, srow = r0;
         if (r0 + lane < r1) slen = rowptr[r0 + lane + 1] - rowptr[r0 + lane];
         int key = (slen << 4) | (15 - (lane & 15)); // longest row, lowest index first
@@ -327,6 +367,25 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         }
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) runs += __shfl_xor(runs, m, WAVE);
+        len_out = b0 - a0;
+        runs_out = runs;
+    };
+    // Rows whose columns come in runs (mesh numberings: nine consecutive columns per neighbour plane) are served well
+    // out of the L2 by the direct kernels, so the LDS-tiled kernel pays later on them: grid-structured rows at 64
+    // columns lose 16 % at 3.2 uses per loaded B row and win 12 % at 5.1 (uniform rows win from 2.75).  A panel under
+    // the lowered bar whose head row fills 60 % of the 4-column blocks it touches needs 1.6 x the bar.
+    if (window_ok && !strong) {
+        int hl = 0, hr = 0;
+        head_row(hl, hr);
+        if (hl > 0 && (float)hl >= 0.6f * 4.0f * (float)hr && (float)nnz < 1.6f * min_density * (float)(last - first + 1))
+            window_ok = false;
+    }
+    bool mfma = false;
+    if (sane && mfma_min_fill <= 1.0f && last < 0x7fff0000) { // (the kernel's end-of-row sentinel is 0x7fffffff)
+        const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
+        int hl = 0, runs = 0;
+        head_row(hl, runs);
+        const int a0 = 0, b0 = hl;
         const bool candidate = b0 > a0 && (float)(b0 - a0) >= mfma_min_fill * 4.0f * (float)runs;
         const int e0 = rowptr[r0], e1 = rowptr[r1]; // the 16 rows' entries are one contiguous run of the CSR arrays
         const int blo = first >> 2;
@@ -367,41 +426,6 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
             }
             mfma = dense_chunks && __builtin_amdgcn_ballot_w64(!in_range) == 0ull &&
                    (float)(e1 - e0) >= need * (float)(r1 - r0) * 4.0f * (float)nblk;
-        }
-    }
-    // Do the rows come in groups that list the same columns (the unknowns of one mesh node in a multi-dof FEM matrix),
-    // and is the group length a multiple of three (3-dof nodes; six dofs are two groups of three)?  Neighbouring rows
-    // at the panel's head are compared entry by entry: the first pair that differs ends the (possibly cut) group the
-    // panel starts in, the pairs that agree behind it measure the next group.  Only lengths 3, 6, 9 feed the
-    // row-merging kernel three rows at a time throughout (groups of four merge half of their triples and lose to the
-    // other kernels; pairs do not merge at all); (row index of a group start) mod 3 rides in the class word, so that
-    // the merging kernel lines its waves up with the groups -- a method-2 row block begins anywhere.
-    bool shared = false;
-    int phase = 0;
-    if (sane && !window_ok && merge_probe) {
-        const int r0 = p * panel_rows;
-        int start = -1, len = 0; // first row of the measured group (relative to r0), rows counted so far
-        for (int k = 0; k < 12; ++k) {
-            if (r0 + k + 2 > rows || k + 2 > panel_rows) break;
-            const int a = rowptr[r0 + k], b = rowptr[r0 + k + 1], c2 = rowptr[r0 + k + 2];
-            bool eq = b - a == c2 - b && b > a;
-            if (eq) {
-                bool differ = false;
-                for (int e = lane; e < b - a; e += WAVE) differ |= colidx[a + e] != colidx[b + e];
-                eq = __builtin_amdgcn_ballot_w64(differ) == 0ull;
-            }
-            if (start < 0) {
-                if (!eq) start = k + 1, len = 1; // row k+1 opens a group
-            } else if (eq) {
-                ++len;
-            } else {
-                break; // the group is rows start .. start + len - 1
-            }
-            if (len > 9) break;
-        }
-        if (start >= 0 && len >= 3 && len <= 9 && len % 3 == 0) {
-            shared = true;
-            phase = (r0 + start) % 3;
         }
     }
     if (lane == 0) {
@@ -1659,6 +1683,7 @@ static void options_parse(Options &o)
     if ((e = getenv("SBLAS_STAGE_RANGE")) && *e) o.stage_range = atoi(e);
     if ((e = getenv("SBLAS_DIRECT_MAP")) && *e) o.direct_map = !strcmp(e, "interleave") ? 1 : !strcmp(e, "contiguous") ? 0 : -1;
     if ((e = getenv("SBLAS_ROWS8_MIN_AVG")) && *e) o.rows8_min_avg = atof(e);
+    if ((e = getenv("SBLAS_WINDOW_DENSITY")) && *e) o.window_density = (float)atof(e);
     if ((e = getenv("SBLAS_SPMM_PANEL_ROWS")) && *e) { /* "<rows>" or "<rows>,<groups>" */
         o.panel_rows = atoi(e);
         o.panel_groups = strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0;
@@ -1762,6 +1787,12 @@ size_t workspace_tail_bytes(int64_t rows)
 }
 // block fill from which a panel goes to the matrix cores (fp64 MFMA and fp64 vector FMA have the same peak on gfx950,
 // so the zero fill of a block is paid in full): measured break-even against the vector kernels, tools/spmm_shapes.py blocks:ROWS:FILL
+// Nonzeros a panel must hold per column of its span to take the LDS-tiled kernel: every row of a B tile it loads is then
+// used that many times on average.  0.42 per 16 rows = 2.5 uses for a 96-row panel -- measured on banded rows, 1 M
+// rows, N = 64 (tools/spmm_shapes.py banded:ROWS:PERROW:HALFBAND with SBLAS_WINDOW_DENSITY): at 1.4 uses the direct
+// kernel wins by 36 %, at 2.1-2.4 the two are within 5 %, from 2.75 on the LDS-tiled kernel wins (6 % ... 70 % at 6 uses,
+// where round 1's bar stood).
+static float window_min_density(int panel_rows) { return options().window_density * (float)panel_rows / 16.0f; }
 static float mfma_min_fill(int variant, int panel_rows, int64_t ldbt)
 {
     if (panel_rows > 16 * MFMA_MAX_WAVES) return 2.0f; // the matrix-core kernel runs one wave per 16 rows of a panel
@@ -1804,7 +1835,7 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
         gen6_plan(rows, info_rows, g);
         const int np = (rows + info_rows - 1) / info_rows;
         hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
-                           nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f,
+                           nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows),
                            mfma_min_fill(variant, info_rows, ldbt), (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr,
                            t.info, t.cls, epoch);
     } else if (!again) {
@@ -1830,7 +1861,7 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     const Tail t = tail_of(Bt, cols, ldbt, rows);
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt),
+                       info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), mfma_min_fill(variant, info_rows, ldbt),
                        (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
@@ -1862,7 +1893,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    info_rows, rowptr, colidx, /* 32-bit buffer offsets inside a wave's rows */ 1 << 24,
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
-                                   (float)info_rows / 16.0f, mfma_min_fill(variant, info_rows, ldbt),
+                                   window_min_density(info_rows), mfma_min_fill(variant, info_rows, ldbt),
                                    (ldbt >= 128 && opt.direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
             // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)

@@ -1235,7 +1235,7 @@ def test_spmm_row_merging_kernel_only_where_three_rows_share_a_pattern(env, dofs
     TAIL_MERGE_EPOCH = 6 in kernels.h); the result is checked either way, for a whole matrix and for an odd row block."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
-    rp, ci, v = synth.queen_like_grid(9000, half_band=1500, dofs=dofs)
+    rp, ci, v = synth.queen_like_grid(24000, half_band=9000, dofs=dofs)        # wide band: no panel fits the LDS-tiled kernel
     K = len(rp) - 1
     n = 128
     rng = np.random.default_rng(dofs)

@@ -6,7 +6,7 @@ one process, median of the rounds), with the panel census and an oracle check of
     blocks[:rows[:fill]]       nd24k-like rows in dense 16 x 4 sub-blocks (synth.block_structured)
     blocksw[:rows[:fill]]      16 x 4 sub-blocks, 80 per row, over a +-50 000 band (direct-class panels)
     queen[:rows]               Queen-like, 40 scattered offsets (synth.queen_like)
-    qgrid[:rows[:dofs]]        Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node unless given
+    qgrid[:rows[:dofs[:hb]]]   Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node and a +-50 000 band unless given
     powerlaw[:rows]            webbase-like row lengths (synth.powerlaw)
 Environment switches of the library can be set per variant as name=ENV1=val1+ENV2=val2."""
 import argparse, os, sys, time
@@ -33,7 +33,8 @@ def make(shape):
         rows = int(parts[1]) if len(parts) > 1 else 300000
         rp, ci, v = synth.queen_like(rows)
     elif kind == "qgrid":
-        rp, ci, v = synth.queen_like_grid(int(parts[1]) if len(parts) > 1 else 300000, dofs=int(parts[2]) if len(parts) > 2 else 3)
+        rp, ci, v = synth.queen_like_grid(int(parts[1]) if len(parts) > 1 else 300000, dofs=int(parts[2]) if len(parts) > 2 else 3,
+                                          half_band=int(parts[3]) if len(parts) > 3 else 50000)
         rows = len(rp) - 1
     elif kind == "banded":
         rows = int(parts[1])
