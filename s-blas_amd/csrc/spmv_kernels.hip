@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 }
 
 // ---------------------------------------------------------------------------------------------
-// SpMV for short and medium rows (5..48 nonzeros per row on average), stream form.  The lanes-per-row kernel gives every row a lane group
+// SpMV for short and medium rows (5..64 nonzeros per row on average), stream form.  The lanes-per-row kernel gives every row a lane group
 // of 4..32 lanes: a 5-nonzero row keeps 4 of 8 lanes busy for two trips, and the stencil-like matrices that have such
 // rows run at 2.6-3.3 TB/s.  Here a 256-thread block owns 256 consecutive rows, i.e. ONE contiguous run of nonzeros:
 // all threads stream it (thread t takes nonzeros t, t + 256, ...; every lane busy, fully coalesced), park the
@@ -455,12 +455,14 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
         }
         // medium rows: R rows per wave, segmented (Queen-like rows, 73 per row: 232 us vs 395 us; banded synthetic rows
         // of 36 / 72 / 90: 122 / 266 / 351 us vs 150 / 339 / 375 us for the lanes-per-row kernel)
-        if (avg > 48.0) SBLAS_SPMV_SEG(4, 5);
-        // short and medium rows (5 < avg <= 48): 256 rows per block streamed through LDS, in runs of up to 6144
+        if (avg > 64.0) SBLAS_SPMV_SEG(4, 5);
+        // short and medium rows (5 < avg <= 64): 256 rows per block streamed through LDS, in runs of up to 6144
         // products (stencil-like rows of 7 / 13 / 27: 108 / 177 / 344 us vs 143 / 277 / 498 us for the lanes-per-row and
         // segmented kernels; banded-random rows of 14 / 20 / 28 / 36 / 48: 46 / 62 / 85 / 116 / 161 vs 49 / 71 / 94 /
-        // 128 / 194).  Above 48 the segmented kernel stays (Queen-like rows of 69: 52 us vs 85 us for the stream form,
-        // which needs three runs per block there); at 5 and below the lanes-per-row kernel is as fast or faster.
+        // 128 / 194; 1 M banded rows of 55 / 70: 207 / 256 us vs 250 / 281 us segmented; Queen-like rows of 73: 251 vs
+        // 256 us).  Rows beyond 96 take the kernel's slow path (a wave per row), so it stops where a spread of row
+        // lengths starts to reach that: Poisson rows of 60 on average tie, of 70 lose 4 %, of 80 7 %, of 90 27 % -- the launcher
+        // only knows the average.  At 5 and below the lanes-per-row kernel is as fast or faster.
         if (avg > 5.0) {
             hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0,
                                s, rows, rowptr, colidx, val, x, alpha, beta, y);

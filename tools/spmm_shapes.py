@@ -8,6 +8,7 @@ one process, median of the rounds), with the panel census and an oracle check of
     queen[:rows]               Queen-like, 40 scattered offsets (synth.queen_like)
     qgrid[:rows[:dofs[:hb]]]   Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node and a +-50 000 band unless given
     powerlaw[:rows]            webbase-like row lengths (synth.powerlaw)
+    uniform:rows:avg           binomial row lengths, columns anywhere (synth.random_csr)
 Environment switches of the library can be set per variant as name=ENV1=val1+ENV2=val2."""
 import argparse, os, sys, time
 import numpy as np, torch
@@ -39,6 +40,9 @@ def make(shape):
     elif kind == "banded":
         rows = int(parts[1])
         rp, ci, v = synth.banded(rows, int(parts[2]), int(parts[3]) if len(parts) > 3 else 2000)
+    elif kind == "uniform":   # binomial row lengths around the average, columns anywhere (synth.random_csr)
+        rows = int(parts[1])
+        rp, ci, v = synth.random_csr(rows, rows, float(parts[2]), sorted_rows=len(parts) > 3)
     elif kind == "powerlaw":
         rows = int(parts[1]) if len(parts) > 1 else 1000000
         rp, ci, v = synth.powerlaw(rows)
