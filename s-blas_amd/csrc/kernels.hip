@@ -839,6 +839,11 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
                              max(__builtin_amdgcn_readlane(take, 32), __builtin_amdgcn_readlane(take, 48)));
                 // (blocks of eight steps with the second half's LDS reads issued ahead of the first half's FMAs were
                 //  tried: no gain)
+                // The LDS-read / FMA blocks run at raised wave priority: a wave that has its operands selected gets the
+                // issue slots ahead of the waves still doing bookkeeping (step 0.2864 -> 0.2781 ms and 0.2690 -> 0.2563 ms on
+                // two boxes; priority 1, 2 or 3 alike; raised during the selection instead, on the loader waves, or on
+                // all consumers with the blocks one level higher: nothing)
+                asm volatile("s_setprio 1" ::: "memory");
                 {
                     const unsigned co = coA;
                     const double gv = gvA;
@@ -855,6 +860,7 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
                     if (mx > 24) { SBLAS_QSTEP4(8, 9, 10, 11); }
                     if (mx > 28) { SBLAS_QSTEP4(12, 13, 14, 15); }
                 }
+                asm volatile("s_setprio 0" ::: "memory");
                 cur[g] += take;
                 // a row that used its whole window and has more: fetch the next windows now and go again (rare:
                 // more than 32 nonzeros of a row inside one 128-column tile)
