@@ -1393,3 +1393,76 @@ def _eight_columns_long_rows(sblas, oracle, torch, dev, synth, n, kind):
         sblas.spmm(rows, cols, A.rowptr, A.colidx, A.val, B, cols, n, alpha, beta, C, rows, ws)
         ref = oracle.spmm(rows, cols, n, *A.h, Bh, Ch.copy(), alpha, beta)
         assert close(C.cpu().numpy(), ref), (n, kind, alpha, beta)
+
+
+def test_spmm_and_spmv_from_two_streams_at_once(env):
+    """Two streams of one device issue calls side by side (own workspace each, no synchronisation in between): the
+    library keeps no per-call state outside the workspace and the epoch counter is atomic, so the calls must not
+    disturb each other -- an LDS-tiled matrix on one stream, a direct-path matrix and an SpMV on the other, ten rounds
+    with fresh B."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    n = 64
+    rp1, ci1, v1 = synth.banded(3000, 120, 400)
+    rp2, ci2, v2 = synth.random_csr(2500, 2500, 30, seed=5, sorted_rows=True, long_row=(9, 2000))
+    A1, A2 = Dev(torch, dev, rp1, ci1, v1, 3000), Dev(torch, dev, rp2, ci2, v2, 2500)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ws1 = torch.empty(sblas.spmm_workspace_bytes(3000, 3000, len(ci1), n) // 8, dtype=torch.float64, device=dev)
+    ws2 = torch.empty(sblas.spmm_workspace_bytes(2500, 2500, len(ci2), n) // 8, dtype=torch.float64, device=dev)
+    rng = np.random.default_rng(12)
+    B1h = [rng.standard_normal(3000 * n) for _ in range(10)]
+    B2h = [rng.standard_normal(2500 * n) for _ in range(10)]
+    B1 = [torch.from_numpy(b).to(dev) for b in B1h]
+    B2 = [torch.from_numpy(b).to(dev) for b in B2h]
+    C1 = [torch.zeros(3000 * n, dtype=torch.float64, device=dev) for _ in range(10)]
+    C2 = [torch.zeros(2500 * n, dtype=torch.float64, device=dev) for _ in range(10)]
+    y2 = [torch.zeros(2500, dtype=torch.float64, device=dev) for _ in range(10)]
+    torch.cuda.synchronize()
+    for k in range(10):
+        sblas.spmm(3000, 3000, A1.rowptr, A1.colidx, A1.val, B1[k], 3000, n, 1.0, 0.0, C1[k], 3000, ws1, stream=s1)
+        sblas.spmm(2500, 2500, A2.rowptr, A2.colidx, A2.val, B2[k], 2500, n, 2.0, 0.0, C2[k], 2500, ws2, stream=s2)
+        sblas.spmv(2500, 2500, A2.rowptr, A2.colidx, A2.val, B2[k][:2500], 1.0, 0.0, y2[k], stream=s2)
+    torch.cuda.synchronize()
+    for k in (0, 4, 9):
+        assert close(C1[k].cpu().numpy(), oracle.spmm(3000, 3000, n, *A1.h, B1h[k], np.zeros(3000 * n), 1.0, 0.0)), k
+        assert close(C2[k].cpu().numpy(), oracle.spmm(2500, 2500, n, *A2.h, B2h[k], np.zeros(2500 * n), 2.0, 0.0)), k
+        assert close(y2[k].cpu().numpy(), oracle.spmv(2500, *A2.h, B2h[k][:2500].copy(), np.zeros(2500), 1.0, 0.0)), k
+
+
+def test_spmm_from_two_host_threads(env):
+    """The reference drives every GPU from its own OpenMP thread (spmm.h:100-104); here two host threads call into the
+    library at once (ctypes releases the GIL), each on its own stream and workspace: the process-wide state (options,
+    epoch counter, per-kernel LDS limits) is guarded, results match the oracle."""
+    import threading
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    n = 128
+    mats = [synth.banded(4000, 150, 500, seed=1), synth.queen_like_grid(6000, half_band=2500)]
+    jobs = []
+    for rp, ci, v in mats:
+        rows = len(rp) - 1
+        A = Dev(torch, dev, rp, ci, v, rows)
+        Bh = np.random.default_rng(rows).standard_normal(rows * n)
+        jobs.append(dict(A=A, rows=rows, Bh=Bh, B=torch.from_numpy(Bh).to(dev), C=torch.zeros(rows * n, dtype=torch.float64, device=dev),
+                         ws=torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), n) // 8, dtype=torch.float64, device=dev),
+                         stream=torch.cuda.Stream(device=dev), err=None))
+    torch.cuda.synchronize()
+
+    def work(j):
+        try:
+            torch.cuda.set_device(dev)
+            for _ in range(20):
+                sblas.spmm(j["rows"], j["rows"], j["A"].rowptr, j["A"].colidx, j["A"].val, j["B"], j["rows"], n, 1.0, 0.0, j["C"],
+                           j["rows"], j["ws"], stream=j["stream"])
+        except Exception as ex:      # surfaced by the main thread
+            j["err"] = ex
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for j in jobs:
+        assert j["err"] is None, j["err"]
+        assert close(j["C"].cpu().numpy(), oracle.spmm(j["rows"], j["rows"], n, *j["A"].h, j["Bh"], np.zeros(j["rows"] * n), 1.0, 0.0))
