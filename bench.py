@@ -191,12 +191,13 @@ def settle(torch, step, max_blocks=25, block=20):
 
 def dominant_kernel_name(S, n, census):
     """Name (as rocprofv3 prints it, without the namespace) of the stage-2 kernel that did most of the panels."""
-    if n <= 8:
-        return "spmm (n=%d)" % n
-    if census["mfma"] >= max(census["windowed"], census["direct"]):
+    ldbt = int(S.lib().sblas_hip_spmm_ldbt(n))
+    if census["mfma"] >= max(census["windowed"], census["direct"]) and census["mfma"] > 0:
         return "spmm_mfma_kernel"
     if census["windowed"] >= census["direct"]:
-        return "spmm_window6_kernel"
+        return "spmm_window6_kernel" if ldbt >= 64 else "spmm_lanes_kernel"
+    if ldbt == 8:
+        return "spmm (n=%d)" % n
     return "spmm_direct_dpp_kernel" if n > 32 else "spmm_direct_dpp_kernel<4>"
 
 
@@ -616,8 +617,8 @@ def main():
     s2 = [e[1].elapsed_time(e[2]) for e in ev]
     t_stage2 = float(np.mean(s2)) * 1e-3
     kernel = dominant_kernel_name(S, n, census)
-    if not kernel.startswith("spmm_window6"):
-        t_dom = None                                 # the launcher's events bracket the LDS-tiled kernel only
+    if not (kernel.startswith("spmm_window6") or kernel.startswith("spmm_lanes")):
+        t_dom = None                                 # the launcher's events bracket the LDS-tiled kernels only
     t_roof = t_dom if t_dom else t_stage2
 
     # correctness guard on this rank's result: C = 1 + steps_total * A*B on 64-row windows (first panel, a middle one,
@@ -662,6 +663,65 @@ def main():
         "cold_ms_per_step": round(cold_ms, 5),      # first ten steps of the process, idle clocks, host wall incl. launches
         "oracle_check": check, "oracle_max_abs_diff": check_err,
     }
+
+    # ---- method 1, STRONG scaling: BASELINE's metric is N = 64 in total, and method 1 hands GPU i the columns
+    # [i * ceil(64 / g), ...) of B and C with the full A (matrix.h:554-568): 32 / 16 / 8 columns per GPU at g = 2 / 4 / 8.
+    # No collective.  With one GPU the same widths are timed one after the other on it (`method1_widths`): the per-GPU
+    # step a g-GPU run sees, measured, not a projection of the g-GPU figure.
+    def time_width(nw, col0, steps, settle_steps):
+        Bref = S.rand0to1(cols * 64)
+        Bw_h = np.ascontiguousarray(Bref[col0 * cols:(col0 + nw) * cols])
+        del Bref
+        Bw = d(Bw_h)
+        Cw = torch.ones(rows * nw, dtype=torch.float64, device=dev)
+        wsw = torch.empty(S.spmm_workspace_bytes(rows, cols, nnz, nw) // 8, dtype=torch.float64, device=dev)
+        stepw = lambda: S.spmm(rows, cols, rowptr, colidx, val, Bw, cols, nw, 1.0, 1.0, Cw, rows, wsw)
+        S.panel_census()
+        stepw()
+        torch.cuda.synchronize()
+        cen = S.panel_census()
+        for _ in range(settle_steps):
+            stepw()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepw()
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        ok, err = check_windows(oracle(), Cw.view(nw, rows), rows, cols, nw, rp, ci, v, Bw_h, 1 + settle_steps + steps,
+                                (0, rows // 3, rows - 64))
+        return el, ok, err, cen
+
+    if n == 64 and world > 1:
+        off, dim = S.partition_dense(64, world, rank)
+        el_s, ok_s, err_s, cen_s = time_width(dim, off, args.steps, 60)
+        t = torch.tensor([el_s, 0.0 if ok_s else 1.0], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_s, bad_s = float(t[0].item()), bool(t[1].item() > 0.5)
+        if bad_s:
+            failures.append("method-1 strong-scaling result does not match the oracle on some rank (rank 0: %g)" % err_s)
+        out["method1_strong"] = {
+            "scaling": "strong", "n_total_cols": 64, "cols_per_gpu": dim, "oracle_check": not bad_s,
+            "gflops": round(2.0 * nnz * 64 * args.steps / el_s / 1e9, 2), "ms_per_step": round(el_s / args.steps * 1e3, 5),
+            "speedup_vs_this_runs_per_gpu_n64_step": round((elapsed / args.steps) / (el_s / args.steps), 3),
+            "panels_rank0": cen_s,
+            "note": "N = 64 total over %d GPUs, no collective; every GPU streams all of A (ideal speed-up at g = 8: 455.5 / 358.7 MB = 1.27x by HBM bytes, SURVEY 8d)" % world,
+        }
+    elif n == 64 and world == 1 and not args.no_extras:
+        widths = {}
+        for g_, nw in ((2, 32), (4, 16), (8, 8)):
+            el_w, ok_w, err_w, cen_w = time_width(nw, 0, args.steps, 100)
+            if not ok_w:
+                failures.append("method-1 width %d does not match the oracle: max diff %g" % (nw, err_w))
+            widths["g%d" % g_] = {"cols_per_gpu": nw, "ms_per_step": round(el_w / args.steps * 1e3, 5),
+                                  "per_gpu_gflops": round(2.0 * nnz * nw * args.steps / el_w / 1e9, 2),
+                                  "job_gflops_if_every_gpu_ran_this_step": round(2.0 * nnz * 64 * args.steps / el_w / 1e9, 2),
+                                  "oracle_check": ok_w, "panels": cen_w}
+        out["method1_widths"] = {"note": "one GPU, the column widths method 1 gives each of g GPUs at N = 64 (matrix.h:554-568); "
+                                         "measured one after the other on this GPU", **widths}
 
     # ---- method 2 with torch.distributed collectives (one process per GPU), informational -------------------------------
     if world > 1 and not args.no_method2:

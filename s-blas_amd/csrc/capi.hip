@@ -69,28 +69,32 @@ int sblas_hip_device_count(void)
     return n;
 }
 
-// narrow = true: the 16- / 32-column tiers (64-bit addressing, the last resort when even a 64-column staging copy
-// would exceed the 32-bit offset window, and what SBLAS_SPMM_MIN_LDBT=0 selects)
-static int64_t ldbt_pick(int64_t n, bool narrow)
+// staged width of an n-column block: 8, 16 (tier16), 32 (tier32), 64 or a multiple of 128.  The 16- / 32-column tiers are
+// also the last resort when even a 64-column staging copy would exceed the 32-bit offset window (chunk_ldbt).
+static int64_t ldbt_pick(int64_t n, bool tier16, bool tier32)
 {
     if (n <= 0) return 0;
     if (n <= 8) return 8;
-    if (n <= 16 && narrow) return 16;
-    if (n <= 32 && narrow) return 32;
+    if (n <= 16 && tier16) return 16;
+    if (n <= 32 && tier32) return 32;
     if (n <= 64) return 64;
     return (n + 127) / 128 * 128; // wide tiles are 128 columns (two per lane)
 }
 
 int64_t sblas_hip_spmm_ldbt(int64_t n)
 {
-    // 9..32 columns run on the 64-column staging copy: row panels that qualify for the LDS-tiled kernel are 2-3x faster
-    // there than in the narrow kernels (banded bench matrix, N = 16 / 32: 0.31 / 0.33 ms against 0.58 / 1.05 ms) and the
-    // direct kernel reads only the first 32 columns of a Bt row (four nonzeros per instruction; Queen-like rows,
-    // N = 16 / 32: 0.45 / 0.46 ms against 0.42 / 0.78 ms).  SBLAS_SPMM_MIN_LDBT=0 restores the 16- and 32-column
-    // kernels (tests, A/B runs).
-    return ldbt_pick(n, sblas::options().min_ldbt < 64);
+    // 8 / 16 / 32 / 64 staged columns for n <= 8 / 16 / 32 / 64: method 1 on 8 / 4 / 2 GPUs hands a GPU exactly these
+    // widths of a 64-column B (matrix.h:554-568), and the narrow LDS-tiled kernel (spmm_lanes_kernel) reads NC * 8 bytes
+    // of LDS per nonzero instead of the 512 of a zero-padded 64-column tile (banded bench matrix, N = 8 / 16 / 32 on the
+    // 64-column path: 0.265 / 0.238 / 0.245 ms).  SBLAS_SPMM_MIN_LDBT=64 puts 9..32 columns back on the 64-column
+    // staging copy (A/B runs, tests).
+    return ldbt_pick(n, sblas::options().tier16, sblas::options().tier32);
 }
-static bool ldbt_ok(int64_t ldbt, int64_t n) { return ldbt == ldbt_pick(n, false) || ldbt == ldbt_pick(n, true); }
+static bool ldbt_ok(int64_t ldbt, int64_t n)
+{
+    return ldbt == ldbt_pick(n, false, false) || ldbt == ldbt_pick(n, true, true) || ldbt == ldbt_pick(n, true, false) ||
+           ldbt == ldbt_pick(n, false, true);
+}
 
 // The kernels address Bt with 32-bit byte offsets, so one stage-2 launch can cover at most 4 GiB of Bt.  The
 // top-level call therefore walks the dense columns in chunks of `w` columns with (cols+1)*ldbt(w)*8 <= 4 GiB
@@ -111,7 +115,7 @@ static int64_t spmm_chunk_cols(int64_t cols, int64_t n)
 static int64_t chunk_ldbt(int64_t cols, int64_t n, int64_t nj)
 {
     const bool forced_narrow = spmm_chunk_cols(cols, n) <= 32 && 8ull * ((uint64_t)cols + 1) * 64ull > bt_byte_limit();
-    return forced_narrow ? ldbt_pick(nj, true) : sblas_hip_spmm_ldbt(nj);
+    return forced_narrow ? ldbt_pick(nj, true, true) : sblas_hip_spmm_ldbt(nj);
 }
 
 size_t sblas_hip_spmm_csr_f64_i32_workspace(int64_t rows, int64_t cols, int64_t nnz, int64_t n)
@@ -216,8 +220,10 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
             range_epoch = pre_epoch;
             range_ldbt = ldbt;
         } else if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
-            spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && ldbt >= 64 && cols > 0 && nnz > 0 && ldb >= cols &&
-            ldbt_ok(ldbt, nj)) {
+            spmm_variant() != sblas::SPMM_VARIANT_LANES &&
+            (ldbt >= 64 || (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE &&
+                            ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull <= 0xffffffffull)) &&
+            cols > 0 && nnz > 0 && ldb >= cols && ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
             DeviceScope scope(dev);
             if (scope.err != hipSuccess) return SBLAS_E_HIP;

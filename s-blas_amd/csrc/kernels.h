@@ -49,7 +49,7 @@ hipError_t launch_spmm_mfma(hipStream_t s, int rows, int cols, const int *rowptr
 struct Options {
     int spmm_variant = SPMM_VARIANT_AUTO;
     char spmv_variant[16] = {0};          // "" = auto
-    int min_ldbt = 64;                    // SBLAS_SPMM_MIN_LDBT: < 64 re-enables the 16- / 32-column staging tiers
+    bool tier16 = true, tier32 = true;    // staged widths 16 / 32 for n <= 16 / 32 (SBLAS_SPMM_MIN_LDBT: 0 = both, 64 = neither: the 64-column copy)
     unsigned long long max_bt_bytes = 0xffffffffull; // SBLAS_SPMM_MAX_BT_BYTES (tests of the column-chunk loop)
     int direct_lds = -1;                  // SBLAS_DIRECT_LDS
     int direct_map = -1;                  // SBLAS_DIRECT_MAP: 1 interleave, 0 contiguous, -1 by span

@@ -102,6 +102,39 @@ __global__ __launch_bounds__(256) void dense_to_rowmajor_kernel(int64_t cols, in
                stage_epoch);
 }
 
+// Stage 1 for narrow blocks (ldbt = NC in {8, 16, 32}): a thread per row of Bt.  The reads of a wave run along k
+// (512 contiguous bytes per column of B), every thread writes its NC * 8 contiguous bytes of Bt, a wave 64 such rows
+// in a row.  (The 32 x 64 tile transposer above spends the time of a 64-column block on any narrower one: 16 us on the
+// bench shape against 2-3 us here.)
+template <int NC>
+__device__ __forceinline__ void stage_rows_narrow(int64_t k0, int64_t cols, int64_t n, const double *__restrict__ B,
+                                                  int64_t ldb, double *__restrict__ Bt, int *__restrict__ tail,
+                                                  int stage_epoch)
+{
+    const int64_t k = k0 + threadIdx.x;
+    double v[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) v[j] = (j < n && k < cols) ? B[k + (int64_t)j * ldb] : 0.0;
+    bool odd = false;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) odd |= (__double2hiint(v[j]) & 0x7ff00000) == 0x7ff00000;
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull && (threadIdx.x & 63) == 0) tail[TAIL_NONFINITE] = stage_epoch;
+    if (k0 == 0 && threadIdx.x == 0) tail[TAIL_STAGE_EPOCH] = stage_epoch;
+    if (k <= cols) { // row `cols` is the all-zero row
+        double2 *dst = reinterpret_cast<double2 *>(Bt + k * NC);
+#pragma unroll
+        for (int j = 0; j < NC / 2; ++j) dst[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    }
+}
+template <int NC>
+__global__ __launch_bounds__(256) void dense_to_rowmajor_narrow_kernel(int64_t cols, int64_t n,
+                                                                      const double *__restrict__ B, int64_t ldb,
+                                                                      double *__restrict__ Bt,
+                                                                      int *__restrict__ tail, int stage_epoch)
+{
+    stage_rows_narrow<NC>((int64_t)blockIdx.x * 256, cols, n, B, ldb, Bt, tail, stage_epoch);
+}
+
 // Stage 1 of a ROW BLOCK (method 2: rows << cols).  A block of a banded matrix refers to a narrow range of columns,
 // so only that range of B needs a row-major copy: at config 5's shape a rank of eight stages 15 % of B instead of
 // all of it.  colrange_kernel finds the exact range (every column index is read: rows need not be sorted), one
@@ -499,6 +532,24 @@ __global__ __launch_bounds__(256) void colrange_classify_kernel(int64_t nnz, int
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx,
                        max_row_len, min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch,
                        bitmaps + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
+}
+// ... and for narrow blocks (no matrix cores, no row-merging probe there)
+template <int NC>
+__global__ __launch_bounds__(256) void stage_classify_narrow_kernel(int64_t cols, int64_t n, const double *__restrict__ B,
+                                                                   int64_t ldb, double *__restrict__ Bt, int rows,
+                                                                   int npanels, int panel_rows,
+                                                                   const int *__restrict__ rowptr,
+                                                                   const int *__restrict__ colidx, int max_row_len,
+                                                                   float min_density, int *__restrict__ tail,
+                                                                   int2 *__restrict__ info, int *__restrict__ cls,
+                                                                   int epoch)
+{
+    const int cblocks = (npanels + 3) / 4;
+    if ((int)blockIdx.x >= cblocks)
+        stage_rows_narrow<NC>((int64_t)((int)blockIdx.x - cblocks) * 256, cols, n, B, ldb, Bt, tail, epoch);
+    else
+        classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
+                       max_row_len, min_density, 2.0f, 0, tail, info, cls, epoch, nullptr);
 }
 // The stage-2 kernels run one after the other, so a matrix whose panels split between the matrix-core kernel and the
 // vector kernels pays for two half-empty launches (block-structured rows at the fill threshold, N = 128: 1.05 ms against
@@ -939,6 +990,328 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Stage 2, LDS-tiled form for NARROW dense blocks (ldbt = NC in {8, 16, 32}: what method 1 hands a GPU when N = 64 is
+// split over 8 / 4 / 2 of them, matrix.h:554-568).
+//
+// Same skeleton as spmm_window6_kernel (row panel x LDS tiles of Bt, four LDS-DMA loader waves, one DPP row per matrix
+// row, 32-entry windows of A fetched a tile ahead with counted vmcnt), but the work inside a visit is turned round: a
+// Bt row is only NC * 8 = 64 ... 256 bytes, so instead of broadcasting entry k of a row to sixteen lanes that each
+// hold four columns, EVERY LANE COMPUTES ITS OWN ENTRY: lane k of DPP row q reads the whole Bt row of entry k of
+// matrix row q (NC / 2 ds_read_b128) and adds its NC products to NC accumulators of its own.  A visit is then
+// two selections, NC / 2 LDS reads and NC FMAs per half window -- no per-entry broadcast steps, no step-count chain --
+// and the partial sums of a matrix row are added up once per panel (LDS atomics into the parked C tile).
+// Tiles are 256 Bt rows (a row of the bench matrix has ~25 entries in one: most of a 32-entry window).  Bank conflicts
+// of the gather: a lane reads its row's 16-byte pieces in rotated order (start = its position in the sixteen-lane
+// group that one LDS cycle serves), and a tile row may be stored CP times over so that lanes of a group never share a
+// bank quad; measured, the kernel is bound by instruction issue, not by the LDS port -- one copy (the least tile DMA)
+// is as fast as two or four (N = 8: 0.121 / 0.122 / 0.129 ms per step, N = 16: 0.144 / 0.143), so CP = 1 ships.
+// Measured on the bench matrix (72 000 rows, 399 per row), whole step: N = 8 0.117-0.121 ms, N = 16 0.143 ms,
+// N = 32 0.204 ms (64-column path of round 2: 0.265 / 0.238 / 0.245 ms).
+// ---------------------------------------------------------------------------------------------
+constexpr int WL_TR = 256;          // Bt rows per LDS tile
+template <int NC, int CP> struct WlGeom {
+    static constexpr int P = NC / 2;                 // 16-byte pieces per Bt row
+    static constexpr unsigned ROWB = NC * 8;         // bytes of a Bt row
+    static constexpr unsigned ROW = CP * ROWB;       // LDS bytes per tile row: CP copies of the Bt row
+    static constexpr int SHIFT = ROW == 64 ? 6 : ROW == 128 ? 7 : 8;
+    static constexpr unsigned TILE = WL_TR * ROW;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)TILE + 512 + 64;
+    static constexpr int LPR = CP * P;               // lanes of a DMA instruction per tile row
+    static constexpr int RPI = 64 / LPR;             // tile rows per DMA instruction (1 KiB)
+    static_assert(ROW == 64 || ROW == 128 || ROW == 256, "copies x row bytes");
+    static_assert(CP * P <= 16, "a lane group has sixteen lanes");
+};
+
+// position of a lane inside the group of sixteen lanes that one LDS cycle of a ds_read_b128 serves
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, the same + 32: MI355X_MICROARCH.md, LDS)
+__device__ __forceinline__ int b128_group_pos(int lane)
+{
+    const int l = lane & 31;
+    if (l < 4) return l;            // group A
+    if (l < 12) return l - 4;       // group B
+    if (l < 16) return l - 8;       // group A: 12-15 -> 4-7
+    if (l < 20) return l - 8;       // group B: 16-19 -> 8-11
+    if (l < 28) return l - 12;      // group A: 20-27 -> 8-15
+    return l - 16;                  // group B: 28-31 -> 12-15
+}
+
+template <int SHIFT>
+__device__ __forceinline__ void lanes_select(int wc, double wv, int tile_lo, int rem, int k, unsigned zero_rel,
+                                             unsigned &co, double &gv, unsigned long long &m)
+{
+    int glo, ghi;
+    asm volatile("v_subrev_u32 %[co], %[tlo], %[wc]\n\t"
+                 "v_cmp_gt_i32 %[m], %[rem], %[k]\n\t"
+                 "v_cmp_gt_u32 vcc, 0x100, %[co]\n\t"
+                 "v_lshlrev_b32 %[co], %[sh], %[co]\n\t"
+                 "s_and_b64 vcc, vcc, %[m]\n\t"
+                 "s_mov_b64 %[m], vcc\n\t"
+                 "v_cndmask_b32 %[co], %[zr], %[co], vcc\n\t"
+                 "v_cndmask_b32 %[glo], 0, %[vlo], vcc\n\t"
+                 "v_cndmask_b32 %[ghi], 0, %[vhi], vcc"
+                 : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
+                 : [tlo] "s"(tile_lo), [wc] "v"(wc), [rem] "v"(rem), [k] "v"(k), [zr] "v"(zero_rel),
+                   [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv)), [sh] "n"(SHIFT)
+                 : "vcc", "scc");
+    gv = __hiloint2double(ghi, glo);
+    static_assert(WL_TR == 256, "the literal of the selection");
+}
+typedef double sblas_d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) sblas_d2 *sblas_lds_d2;
+// The products of one half window: lane-own entry x its Bt row.  Lane l reads the row's pieces in the order
+// rot, rot + 1, ..., P - 1, 0, ..., rot - 1 (rot = its position in the LDS lane group), from copy `copy` of the row: the
+// sixteen lanes of a group then sit on sixteen different bank quads whatever rows they read.  acc[j] therefore holds
+// the column pair (j + rot) mod P.  wrap[j] = lanes whose j-th piece is past the end of the row (they read from
+// `hi` = lo - row bytes).
+template <int NC>
+__device__ __forceinline__ void lanes_fma(unsigned lo, double gv, const unsigned long long (&wrap)[NC / 2],
+                                          sblas_d2 (&acc)[NC / 2])
+{
+    constexpr int P = NC / 2, CH = P < 4 ? P : 4;
+    const unsigned hi = lo - (unsigned)(NC * 8);
+#pragma unroll
+    for (int j0 = 0; j0 < P; j0 += CH) {
+        sblas_d2 b[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int j = j0 + u;
+            unsigned a = lo;
+            if (j > 0) asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(a) : "v"(lo), "v"(hi), "s"(wrap[j]));
+            b[u] = ((sblas_lds_d2)(uintptr_t)a)[j];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            acc[j0 + u].x = fma(gv, b[u].x, acc[j0 + u].x);
+            acc[j0 + u].y = fma(gv, b[u].y, acc[j0 + u].y);
+        }
+    }
+}
+// one row of a narrow block, straight from Bt in global memory (the per-panel fallback; kept out of line and eight
+// columns at a time so that it does not set the kernel's register count): every lane takes every 64th entry, the 64
+// partial sums are folded at the end.  Lane j < NC returns column j.
+template <int NC>
+__device__ __noinline__ double row_direct_narrow(const int *__restrict__ colidx, const double *__restrict__ val,
+                                                 const double *__restrict__ Bt, int lane, int p0, int p1)
+{
+    double mine = 0.0;
+    for (int j0 = 0; j0 < NC; j0 += 8) {
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.0;
+        for (int p = p0 + lane; p < p1; p += WAVE) {
+            const double v = val[p];
+            const double *br = Bt + (size_t)colidx[p] * NC + j0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = fma(v, br[j], a[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double s = a[j];
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, WAVE);
+            if (lane == j0 + j) mine = s;
+        }
+    }
+    return mine;
+}
+
+template <int NC, int CP, int G>
+__global__ __launch_bounds__(1024) void spmm_lanes_kernel(
+    int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
+    const double *__restrict__ val, const double *__restrict__ Bt, int n, double alpha, double beta,
+    double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int2 *__restrict__ info,
+    const int *__restrict__ cls, int panel_rows, int nnz)
+{
+    using Geo = WlGeom<NC, CP>;
+    constexpr int P = Geo::P;
+    constexpr unsigned WL_TILE = Geo::TILE;
+    constexpr int RW = 4 * G, RMAX = 12 * RW;
+    static_assert(NC == 8 || NC == 16 || NC == 32, "8, 16 or 32 dense columns");
+    static_assert(G >= 1 && G <= 3, "one to three groups of four rows per wave (counted vmcnt waits: 4 G)");
+    static_assert((size_t)NC * (RMAX + 1) * sizeof(double) <= 2 * (size_t)WL_TILE, "C tile must fit in the (dead) B tiles");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    char *sm = reinterpret_cast<char *>(smem);
+    double *zero_row = reinterpret_cast<double *>(sm + 2 * WL_TILE); // 512 bytes
+    int *sm_i = reinterpret_cast<int *>(sm + 2 * WL_TILE + 512);     // [0] = bad
+
+    const int panel = xcd_contiguous_panel(blockIdx.x, npanels);
+    if (!owns_window(tail, cls, panel)) return; // another kernel owns this panel
+    const int2 span = info[panel];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_uniform(tid >> 6);
+    const int row0 = panel * panel_rows;
+    const int t_lo = span.x / WL_TR, t_hi = span.y / WL_TR;
+    const bool loader = wave >= 12;
+    const bool active = !loader && wave * RW < panel_rows;
+
+    if (tid < 64) zero_row[tid] = 0.0;
+    if (tid == 0) sm_i[0] = 0;
+
+    sblas_d2 acc[G][P];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < P; ++j) acc[g][j] = sblas_d2{0.0, 0.0};
+
+    // ---- tile DMA: loader wave lw moves Bt rows 64 lw .. 64 lw + 63 of a tile, RPI rows (1 KiB of LDS) per
+    // instruction: lane l fills slot l % LPR of row l / LPR with piece (l % LPR) mod P of that Bt row -- the row is stored
+    // CP times over.  Rows past the end of B are clamped to row `cols`, the all-zero row of the workspace.
+    const char *bt_bytes = reinterpret_cast<const char *>(Bt);
+    const unsigned dma_piece = (unsigned)((lane % Geo::LPR) & (P - 1)) * 16u;
+    const unsigned dma_voff = (unsigned)(lane / Geo::LPR) * Geo::ROWB + dma_piece;
+    int dummy = 0;
+    auto dma_tile = [&](int t, int buf) {
+        const int lw = wave - 12;
+        const int r0 = t * WL_TR + lw * 64;
+        const unsigned lds0 = (unsigned)(uintptr_t)(sm + (size_t)buf * WL_TILE) + (unsigned)lw * (64u * Geo::ROW);
+        constexpr int NI = 64 / Geo::RPI;
+        if (r0 + 63 <= cols) {
+            const char *p = bt_bytes + (size_t)r0 * Geo::ROWB;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                dma_rows_scalar(lds0 + i * 1024u, dma_voff, p + (size_t)(Geo::RPI * i) * Geo::ROWB);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const unsigned brow = (unsigned)min(r0 + Geo::RPI * i + lane / Geo::LPR, cols);
+                dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)brow * Geo::ROWB + dma_piece);
+            }
+        }
+    };
+    if (loader) dma_tile(t_lo, 0);
+
+    const int k = lane & 15, q = lane >> 4;
+    // this lane's place in its LDS lane group: which copy of a tile row it reads and where in the row it starts
+    const int gpos = b128_group_pos(lane);
+    const int rot = gpos & (P - 1), copy = (gpos / P) % CP;
+    const unsigned lane_off = (unsigned)copy * Geo::ROWB + (unsigned)rot * 16u;
+    unsigned long long wrap[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) wrap[j] = __builtin_amdgcn_ballot_w64(j + rot >= P);
+
+    const int wrow = min(row0 + wave * RW, rows);
+    const int wstart = wave_uniform(rowptr[wrow]);
+    const sblas_rsrc_t rc = make_rsrc(colidx + wstart, 4u, (unsigned)(nnz - wstart));
+    const sblas_rsrc_t rv = make_rsrc(val + wstart, 8u, (unsigned)(nnz - wstart));
+    int cur[G], end[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int rr = wave * RW + 4 * g + q;
+        const int row = row0 + rr;
+        cur[g] = end[g] = 0;
+        if (rr < panel_rows && row < rows) {
+            cur[g] = rowptr[row] - wstart;
+            end[g] = rowptr[row + 1] - wstart;
+        }
+    }
+    unsigned long long viol = 0ull;
+    int wca[G], wcb[G];
+    double wva[G], wvb[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads(); // P
+    for (int t = t_lo; t <= t_hi; ++t) {
+        const int cbuf = (t - t_lo) & 1;
+        if (loader && t < t_hi) dma_tile(t + 1, cbuf ^ 1);
+        const int tile_lo = t * WL_TR;
+        const unsigned tile_base = (unsigned)(uintptr_t)(sm + (size_t)cbuf * WL_TILE);
+        const unsigned lb = tile_base + lane_off;
+        const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+        auto visit = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            window_wait6<4 * (G - 1)>(wca[g], wva[g], wcb[g], wvb[g]);
+            for (;;) {
+                const int rem = end[g] - cur[g];
+                unsigned coA, coB;
+                double gvA, gvB;
+                unsigned long long mA, mB;
+                lanes_select<Geo::SHIFT>(wca[g], wva[g], tile_lo, rem, k, zero_rel, coA, gvA, mA);
+                lanes_select<Geo::SHIFT>(wcb[g], wvb[g], tile_lo, rem - 16, k, zero_rel, coB, gvB, mB);
+                const unsigned fa = q < 2 ? (unsigned)mA : (unsigned)(mA >> 32);
+                const unsigned fb = q < 2 ? (unsigned)mB : (unsigned)(mB >> 32);
+                const int sh = (q & 1) * 16;
+                const int take = __popc((fa >> sh) & 0xffffu) + __popc((fb >> sh) & 0xffffu);
+                // with ascending columns the entries of this tile are exactly the first `take` entries of the window
+                viol |= mA ^ __builtin_amdgcn_ballot_w64(k < take);
+                viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
+                asm volatile("s_setprio 1" ::: "memory");
+                if (mA != 0ull) lanes_fma<NC>(lb + coA, gvA, wrap, acc[g]);
+                asm volatile("" ::: "memory");
+                if (mB != 0ull) lanes_fma<NC>(lb + coB, gvB, wrap, acc[g]);
+                asm volatile("s_setprio 0" ::: "memory");
+                cur[g] += take;
+                const bool more = take >= 32 && cur[g] < end[g];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(more) == 0ull, 1)) break;
+                window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+                window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]);
+            }
+            window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+        };
+        if (active) {
+            visit(std::integral_constant<int, 0>{});
+            if constexpr (G > 1) visit(std::integral_constant<int, 1>{});
+            if constexpr (G > 2) visit(std::integral_constant<int, 2>{});
+        }
+        if (loader) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory"); // the tile has landed
+        __syncthreads(); // E_t
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]);
+    int bad = viol != 0ull ? 1 : 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        if (__builtin_amdgcn_ballot_w64(cur[g] < end[g]) != 0ull) bad = 1;
+    if (bad && lane == 0) atomicOr(&sm_i[0], 1);
+    // the C tile [NC][RMAX + 1] takes the place of the (now dead) B tiles; the lanes' partial sums are ADDED into it
+    double *ctile = smem;
+    __syncthreads(); // V: every wave is done with the tiles
+    const bool fell_back = sm_i[0] != 0;
+    if (tid == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
+    if (!fell_back) {
+        for (int i = tid; i < NC * (RMAX + 1); i += 1024) ctile[i] = 0.0;
+        __syncthreads();
+        if (!loader) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int rr = wave * RW + 4 * g + q;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int pc = (j + rot) & (P - 1); // the column pair acc[g][j] holds
+                    unsafeAtomicAdd(&ctile[(2 * pc) * (RMAX + 1) + rr], acc[g][j].x);
+                    unsafeAtomicAdd(&ctile[(2 * pc + 1) * (RMAX + 1) + rr], acc[g][j].y);
+                }
+            }
+        }
+    } else if (!loader) {
+        for (int j = 0; j < RW; ++j) { // (wave-uniform)
+            const int rr = wave * RW + j;
+            const int row = row0 + rr;
+            int a = 0, b = 0;
+            if (rr < panel_rows && row < rows) {
+                a = wave_uniform(rowptr[row]);
+                b = wave_uniform(rowptr[row + 1]);
+            }
+            const double s = row_direct_narrow<NC>(colidx, val, Bt, lane, a, b);
+            if (lane < NC) ctile[lane * (RMAX + 1) + rr] = s;
+        }
+    }
+    __syncthreads(); // F
+    const int nrows = min(panel_rows, rows - row0);
+    const int ncols = min(NC, n);
+    for (int idx = tid; idx < NC * panel_rows; idx += 1024) {
+        const int r = idx % panel_rows, j = idx / panel_rows;
+        if (r < nrows && j < ncols) {
+            double *dst = C + (int64_t)j * ldc + (row0 + r);
+            const double sres = alpha * ctile[j * (RMAX + 1) + r];
+            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Stage 2, direct form with DPP broadcast (any matrix; no assumption on column order or locality).
 //
 // A wave owns a row and a 128-column tile of C: every lane holds TWO adjacent columns, so a Bt row segment
@@ -1286,19 +1659,29 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
                                                                   const double *__restrict__ val,
                                                                   const double *__restrict__ Bt, int n,
                                                                   double alpha, double beta,
-                                                                  double *__restrict__ C, int64_t ldc)
+                                                                  double *__restrict__ C, int64_t ldc,
+                                                                  const int *__restrict__ tail,
+                                                                  const int *__restrict__ cls, int info_panel_rows,
+                                                                  int epoch)
 {
     constexpr int GROUPS = 256 / G;
     constexpr int RPG = PANEL_ROWS / GROUPS; // rows per group
     static_assert(RPG >= 1, "panel too small for this group width");
     __shared__ double ctile[G][PANEL_ROWS + 1];
+    __shared__ int row_mine[PANEL_ROWS];
+    if (cls != nullptr && nothing_direct(tail, epoch)) return; // every panel went to the LDS-tiled kernel
     const int l = threadIdx.x % G, grp = threadIdx.x / G;
     const int row0 = blockIdx.x * PANEL_ROWS;
     for (int rr = 0; rr < RPG; ++rr) {
         const int r = grp * RPG + rr;
         const int row = row0 + r;
         double acc = 0.0;
-        if (row < rows) {
+        bool mine = row < rows;
+        if (cls && mine) {
+            mine = owns_direct(tail, cls, row / info_panel_rows);
+            if (mine && l == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
+        }
+        if (mine) {
             const int p0 = rowptr[row], p1 = rowptr[row + 1];
             int p = p0;
             for (; p + 4 <= p1; p += 4) {
@@ -1309,12 +1692,13 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
             for (; p < p1; ++p) acc = fma(val[p], Bt[(int64_t)colidx[p] * G + l], acc);
         }
         ctile[l][r] = acc;
+        if (l == 0) row_mine[r] = mine ? 1 : 0;
     }
     __syncthreads();
     const int nrows = min(PANEL_ROWS, rows - row0);
     for (int idx = threadIdx.x; idx < G * PANEL_ROWS; idx += 256) {
         const int r = idx % PANEL_ROWS, j = idx / PANEL_ROWS;
-        if (r < nrows && j < n) {
+        if (r < nrows && j < n && row_mine[r]) {
             double *dst = C + (int64_t)j * ldc + (row0 + r);
             const double s = alpha * ctile[j][r];
             *dst = (beta == 0.0) ? s : fma(beta, *dst, s);
@@ -1466,11 +1850,17 @@ __global__ __launch_bounds__(256) void spmm_rows8_kernel(int rows, int cols, con
                                                         const int *__restrict__ colidx,
                                                         const double *__restrict__ val,
                                                         const double *__restrict__ Bt, int n, double alpha,
-                                                        double beta, double *__restrict__ C, int64_t ldc)
+                                                        double beta, double *__restrict__ C, int64_t ldc,
+                                                        const int *__restrict__ tail, const int *__restrict__ cls,
+                                                        int info_panel_rows, int epoch)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave_uniform(threadIdx.x >> 6);
     if (row >= rows) return;
+    if (cls != nullptr) { // rows of panels the LDS-tiled kernel owns are skipped (a row per wave: wave-uniform)
+        if (nothing_direct(tail, epoch) || !owns_direct(tail, cls, row / info_panel_rows)) return;
+        if (lane == 0 && row % info_panel_rows == 0) atomicAdd(&g_panel_stats[1], 1ull);
+    }
     const int p0 = wave_uniform(rowptr[row]), p1 = wave_uniform(rowptr[row + 1]);
     double a[8];
 #pragma unroll
@@ -1679,7 +2069,7 @@ static void options_parse(Options &o)
     if ((e = getenv("SBLAS_SPMV_VARIANT")) && *e && strcmp(e, "auto")) {
         strncpy(o.spmv_variant, e, sizeof o.spmv_variant - 1);
     }
-    if ((e = getenv("SBLAS_SPMM_MIN_LDBT")) && *e) o.min_ldbt = atoi(e);
+    if ((e = getenv("SBLAS_SPMM_MIN_LDBT")) && *e) o.tier16 = o.tier32 = atoi(e) < 64;
     if ((e = getenv("SBLAS_SPMM_MAX_BT_BYTES")) && *e) {
         const unsigned long long v = strtoull(e, nullptr, 10);
         if (v >= 4096 && v < 0xffffffffull) o.max_bt_bytes = v;
@@ -1767,6 +2157,43 @@ static void gen6_plan(int rows, int &info_rows, int &gen6_g)
     }
 }
 
+// Panel height of the narrow LDS-tiled kernel: twelve consumer waves of G groups of four rows; G is capped by the
+// registers NC accumulators per group take (8 columns: 3, 16 and 32: 1).
+static void lanes_plan(int rows, int ldbt, int &info_rows, int &groups)
+{
+    const int ncu = compute_units();
+    const int gmax = ldbt <= 8 ? 3 : ldbt <= 16 ? 2 : 1;
+    long best_cost = -1;
+    info_rows = 48;
+    groups = 1;
+    for (int g = 1; g <= gmax; ++g)
+        for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
+            if (r < SPMM_MIN_PANEL_ROWS) continue;
+            const long panels = (rows + r - 1) / r;
+            const long cost = ((panels + ncu - 1) / ncu) * (long)(r + 40);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                info_rows = r;
+                groups = g;
+            }
+        }
+    const Options &opt = options();
+    if (opt.panel_rows > 0) { /* experiments */
+        const int r = opt.panel_rows, g = opt.panel_groups ? opt.panel_groups : 1;
+        if (g >= 1 && g <= gmax && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) {
+            info_rows = r;
+            groups = g;
+        }
+    }
+}
+
+// the panel height the classifier and the stage-2 kernels of a call agree on
+static void panel_plan(int rows, int64_t ldbt, int &info_rows, int &groups)
+{
+    if (ldbt < 64) lanes_plan(rows, (int)ldbt, info_rows, groups);
+    else gen6_plan(rows, info_rows, groups);
+}
+
 static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts and one staging pass (see classify_panel)
 
 // The workspace behind the staging copy (kernels.h): header ints, one span per panel, one class per panel.
@@ -1819,8 +2246,16 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
 {
     dim3 grid((unsigned)((cols + 1 + STAGE_K - 1) / STAGE_K), (unsigned)((ldbt + 63) / 64));
     int *hdr = reinterpret_cast<int *>(Bt + (size_t)(cols + 1) * (size_t)ldbt);
-    hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, hdr,
-                       g_epoch.fetch_add(1, std::memory_order_relaxed));
+    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    const dim3 ngrid((unsigned)((cols + 1 + 255) / 256));
+    if (ldbt == 8)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<8>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else if (ldbt == 16)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<16>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else if (ldbt == 32)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<32>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else
+        hipLaunchKernelGGL(dense_to_rowmajor_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, hdr, epoch);
     return hipGetLastError();
 }
 
@@ -1838,7 +2273,7 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
     const int epoch = again ? *epoch_out : g_epoch.fetch_add(1, std::memory_order_relaxed);
     if (!again && classify) {
         int info_rows = 0, g = 2;
-        gen6_plan(rows, info_rows, g);
+        panel_plan(rows, ldbt, info_rows, g);
         const int np = (rows + info_rows - 1) / info_rows;
         hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
                            nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows),
@@ -1860,14 +2295,27 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
                                  int *epoch_out)
 {
     int info_rows = 0, g = 2;
-    gen6_plan(rows, info_rows, g);
+    panel_plan(rows, ldbt, info_rows, g);
     const int np = (rows + info_rows - 1) / info_rows;
     const int stage_blocks = (int)((cols + 1 + STAGE_K - 1) / STAGE_K);
     const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
     const Tail t = tail_of(Bt, cols, ldbt, rows);
+    if (ldbt < 64) {
+        const dim3 ngrid((unsigned)((cols + 1 + 255) / 256 + (np + 3) / 4));
+#define SBLAS_STAGE_NARROW(NC)                                                                                         \
+    hipLaunchKernelGGL(stage_classify_narrow_kernel<NC>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, rows, np, info_rows, \
+                       rowptr, colidx, 1 << 24, window_min_density(info_rows), t.hdr, t.info, t.cls, epoch)
+        if (ldbt == 8) SBLAS_STAGE_NARROW(8);
+        else if (ldbt == 16) SBLAS_STAGE_NARROW(16);
+        else SBLAS_STAGE_NARROW(32);
+#undef SBLAS_STAGE_NARROW
+        *epoch_out = epoch;
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), mfma_min_fill(variant, info_rows, ldbt),
+                       info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows),
+                       ldbt < 64 ? 2.0f : mfma_min_fill(variant, info_rows, ldbt),
                        (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
@@ -1972,22 +2420,75 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             }
         }
     } else {
+        // ---- narrow dense blocks (ldbt = 8 / 16 / 32): LDS-tiled lane-per-entry kernel on the panels that qualify,
+        // a direct kernel on the rest
+        const Tail t = tail_of(Bt, cols, ldbt, rows);
+        // the 16- / 32-column direct kernel addresses Bt with 32-bit byte offsets
+        const bool wide_offsets = ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull;
+        const bool classified = !wide_offsets && variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
+                                variant != SPMM_VARIANT_LANES;
+        const bool preclassified = pre_epoch != 0 && classified;
+        const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
+        const int *cls = nullptr;
+        int info_rows = 1;
+        if (classified) {
+            int g = 2;
+            lanes_plan(rows, (int)ldbt, info_rows, g);
+            const int np = (rows + info_rows - 1) / info_rows;
+            if (!preclassified)
+                hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
+                                   info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), 2.0f, 0, t.hdr, t.info,
+                                   t.cls, epoch);
+            KernelEvents *kev = kernel_events_slot();
+            if (kev) (void)hipEventRecord(kev->a, s);
+#define SBLAS_LAUNCH_LANES(NC, CP, GG)                                                                                 \
+    do {                                                                                                              \
+        raise_dynamic_lds((const void *)spmm_lanes_kernel<NC, CP, GG>, WlGeom<NC, CP>::LDS_BYTES);                    \
+        hipLaunchKernelGGL((spmm_lanes_kernel<NC, CP, GG>), dim3((unsigned)np), dim3(1024), (WlGeom<NC, CP>::LDS_BYTES), s, \
+                           rows, cols, np, rowptr, colidx, val, Bt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls,      \
+                           info_rows, (int)nnz);                                                                      \
+    } while (0)
+            const int cp = opt.tune[0]; /* experiments: copies of a Bt row in the LDS tile */
+            if (ldbt == 8) {
+                if (cp == 4) { if (g == 3) SBLAS_LAUNCH_LANES(8, 4, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 4, 2); else SBLAS_LAUNCH_LANES(8, 4, 1); }
+                else if (cp == 2) { if (g == 3) SBLAS_LAUNCH_LANES(8, 2, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 2, 2); else SBLAS_LAUNCH_LANES(8, 2, 1); }
+                else { if (g == 3) SBLAS_LAUNCH_LANES(8, 1, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 1, 2); else SBLAS_LAUNCH_LANES(8, 1, 1); }
+            } else if (ldbt == 16) {
+                if (cp == 2) { if (g == 2) SBLAS_LAUNCH_LANES(16, 2, 2); else SBLAS_LAUNCH_LANES(16, 2, 1); }
+                else { if (g == 2) SBLAS_LAUNCH_LANES(16, 1, 2); else SBLAS_LAUNCH_LANES(16, 1, 1); }
+            } else {
+                SBLAS_LAUNCH_LANES(32, 1, 1);
+            }
+#undef SBLAS_LAUNCH_LANES
+            if (kev) {
+                (void)hipEventRecord(kev->b, s);
+                kev->recorded = true;
+            }
+            cls = t.cls;
+        }
         const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
-        if (ldbt == 32) {
+        if (ldbt >= 16 && !wide_offsets && variant != SPMM_VARIANT_LANES) {
+            // the row-per-wave kernel, four nonzeros per instruction: sixteen lanes x 16 bytes per nonzero (with 16 staged
+            // columns the upper eight lanes of a DPP row read past the Bt row, into columns that are never stored)
+            const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
+            hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), 0, s, rows,
+                               cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
+                               opt.direct_map, epoch);
+        } else if (ldbt == 32) {
             hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<32>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx, val,
-                               Bt, n, alpha, beta, C, ldc);
+                               Bt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows, epoch);
         } else if (ldbt == 16) {
             hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<16>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx, val,
-                               Bt, n, alpha, beta, C, ldc);
+                               Bt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows, epoch);
         } else if (avg_row >= opt.rows8_min_avg && variant != SPMM_VARIANT_LANES) {
             // n <= 8, long rows: a wave per row, eight sums per lane (banded-random rows, band +-20000, 600 k rows,
             // N = 8: 64 / 128 / 200 / 300 per row: the lane groups win by 25 / 30 / 2 / 0 %; bench matrix, 399 per row,
             // band +-2000: the wave per row wins by 20 % -- tools/rows8_threshold.py)
             hipLaunchKernelGGL(spmm_rows8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, rows, cols, rowptr,
-                               colidx, val, Bt, n, alpha, beta, C, ldc);
+                               colidx, val, Bt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows, epoch);
         } else {
             hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<8>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx, val,
-                               Bt, n, alpha, beta, C, ldc);
+                               Bt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows, epoch);
         }
     }
     return hipGetLastError();
