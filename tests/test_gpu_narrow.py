@@ -74,7 +74,7 @@ def test_narrow_fallback_on_unsorted_rows(env, n, damage):
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
     rows = 600
-    rp, ci, v = synth.banded(rows, 50, 120)
+    rp, ci, v = synth.banded(rows, 50, 120 if n == 16 else 400)      # rows inside one 256-row tile / across several
     ci, v = ci.copy(), v.copy()
     rng = np.random.default_rng(11)
     if damage == "all_descending":
@@ -170,10 +170,10 @@ def test_narrow_census_and_every_panel_height(env, panel_rows_env, n, setting):
         return st
 
     rows = 10 * pr - 7                                                    # the last panel is short
-    rp, ci, v = synth.banded(rows, 60, 150)
+    rp, ci, v = synth.banded(rows, 60, 400)                               # rows span three or four 256-row tiles
     assert run(rp, ci, v, rows, rows) == (10, 0, 0)                       # every panel through LDS
     ci2, v2 = ci.copy(), v.copy()
-    r = 2 * pr + 4
+    r = 2 * pr + 4                                                        # (far from the matrix edges: a full-width row)
     ci2[rp[r]:rp[r + 1]] = ci2[rp[r]:rp[r + 1]][::-1]                     # one descending row in panel 2
     v2[rp[r]:rp[r + 1]] = v2[rp[r]:rp[r + 1]][::-1]
     assert run(rp, ci2, v2, rows, rows) == (9, 0, 1)                      # that panel recomputed, the others not
