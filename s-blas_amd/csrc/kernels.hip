@@ -766,7 +766,13 @@ template <int N> __device__ __forceinline__ void vm_wait6()
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int G>
+// NH = column halves per workgroup.  NH = 1: a 64-column tile of C (grid.y = ldbt / 64).  NH = 2 (128+ staged columns):
+// the workgroup owns 128 columns and walks every 128-row tile of B twice -- columns 0-63, then 64-127, each through the
+// same two LDS buffers -- and the second pass REUSES the first pass's selection (offsets, values, counts): the window
+// wait, the two selections, the counting, the order check, the cursor update and the next window fetch are paid once per
+// (rows, tile) visit instead of once per 64 columns (with grid.y = ldbt / 64 every 64-column slice re-streams A's windows
+// and redoes all of it: N = 128 cost exactly twice N = 64).
+template <int G, int NH>
 __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
@@ -775,6 +781,7 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
 {
     constexpr int RW = 4 * G, RMAX = 16 * RW;
     static_assert(G == 2 || G == 3, "two or three groups per wave (the counted vmcnt waits are 4 G)");
+    static_assert(NH == 1 || NH == 2, "one or two 64-column halves per workgroup");
     static_assert(64 * (RMAX + 1) <= 2 * W2_TILE, "C tile must fit in the (dead) B tile buffers");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *zero_row = smem + 2 * W2_TILE;
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     const int lane = tid & 63;
     const int wave = wave_uniform(tid >> 6);
     const int row0 = panel * panel_rows;
-    const int col0 = blockIdx.y * 64;
+    const int col0 = blockIdx.y * (64 * NH);
     const unsigned ld32 = (unsigned)ldbt;
     const int t_lo = span.x / W2_ROWS, t_hi = span.y / W2_ROWS;
     // waves 12-15 load the tiles, waves 0-11 consume (a wave that did both had its window loads retire behind its own
@@ -799,38 +806,41 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
 
-    double acc[G][4];
+    double acc[NH][G][4];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][g][j] = 0.0;
 
     // ---- tile DMA: loader wave lw (= wave - 12) moves Bt rows 32 lw .. 32 lw + 31 of a tile: 16 instructions of two
     // rows each (lanes 0-31 the first, lanes 32-63 the second); tile row j lives at LDS byte j * 512.  Rows past the end
     // of B are clamped to row `cols`, the all-zero row of the workspace (scalar addresses when all 32 rows exist)
     const unsigned ldb8 = ld32 * 8u;
-    const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row
+    const unsigned piece_off = (unsigned)(col0 + ((lane & 31) << 1)) * 8u; // bytes inside a Bt row (column half 0)
     const unsigned pair_off = (unsigned)(lane >> 5) * ldb8 + piece_off;
     const char *bt_bytes = reinterpret_cast<const char *>(Bt);
     int dummy = 0;
-    // instructions i0 .. i1-1 of the wave's share
-    auto dma_part = [&](int t, int buf, int i0, int i1) {
+    // tile t, column half h -> buffer buf
+    auto dma_part = [&](int t, int h, int buf) {
         const int lw = wave - 12;
         const int r0 = t * W2_ROWS + lw * 32;
         const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)lw * 16384u;
+        const unsigned hoff = (unsigned)h * 512u;
         if (r0 + 31 <= cols) {
-            const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8);
-            for (int i = i0; i < i1; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
+            const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8) + hoff;
+            for (int i = 0; i < 16; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
         } else {
-            for (int i = i0; i < i1; ++i) {
+            for (int i = 0; i < 16; ++i) {
                 const unsigned brow = (unsigned)min(r0 + 2 * i + (lane >> 5), cols);
-                dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off));
+                dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off + hoff));
             }
         }
     };
 
     // the first tile does not depend on the row pointers: fetch it while they are on their way
-    if (loader) dma_part(t_lo, 0, 0, 16);
+    if (loader) dma_part(t_lo, 0, 0);
 
     const int k = lane & 15, q = lane >> 4;
     // per-lane row state, relative to the first nonzero of the wave's rows (base of the two descriptors)
@@ -852,84 +862,129 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     unsigned long long viol = 0ull; // lanes whose entry broke the "entries of a tile = window prefix" expectation
     int wca[G], wcb[G];
     double wva[G], wvb[G];
+    // NH = 2: what the first half's visit selected, kept for the second half (one round; a visit that needed several
+    // window rounds -- `replay` -- walks them again)
+    unsigned s_coA[G], s_coB[G];
+    double s_gvA[G], s_gvB[G];
+    int s_take[G], s_mx[G];
+    bool replay[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        s_coA[g] = s_coB[g] = 0u;
+        s_gvA[g] = s_gvB[g] = 0.0;
+        s_take[g] = s_mx[g] = 0;
+        replay[g] = false;
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
     // everything lands before the loop starts, so its counted waits (written for the steady state) hold from the
     // first tile on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads(); // P
+    int step = 0;
     for (int t = t_lo; t <= t_hi; ++t) {
-        const int cbuf = (t - t_lo) & 1;
-        // next tile (that buffer was last read before the previous barrier)
-        if (loader && t < t_hi) dma_part(t + 1, cbuf ^ 1, 0, 16);
         const int tile_lo = t * W2_ROWS;
-        const unsigned tile_base = (unsigned)(uintptr_t)(smem + cbuf * W2_TILE);
-        const unsigned lb = tile_base + (unsigned)k * 16u;
-        const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
-        auto visit = [&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            // younger than this group's windows: the other groups' windows (4 each)
-            window_wait6<4 * (G - 1)>(wca[g], wva[g], wcb[g], wvb[g]);
-            double &q0 = acc[g][0], &q1 = acc[g][1], &q2 = acc[g][2], &q3 = acc[g][3];
-            for (;;) {
-                const int rem = end[g] - cur[g];
-                unsigned coA, coB;
-                double gvA, gvB;
-                unsigned long long mA, mB;
-                window_select6(wca[g], wva[g], tile_lo, rem, k, zero_rel, coA, gvA, mA);
-                window_select6(wcb[g], wvb[g], tile_lo, rem - 16, k, zero_rel, coB, gvB, mB);
-                // entries of this tile per matrix row (= per DPP row), as a per-lane value
-                const unsigned fa = q < 2 ? (unsigned)mA : (unsigned)(mA >> 32);
-                const unsigned fb = q < 2 ? (unsigned)mB : (unsigned)(mB >> 32);
-                const int sh = (q & 1) * 16;
-                const int take = __popc((fa >> sh) & 0xffffu) + __popc((fb >> sh) & 0xffffu);
-                // with ascending columns they are exactly the first `take` entries of the row's window
-                viol |= mA ^ __builtin_amdgcn_ballot_w64(k < take);
-                viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
-                int mx = max(max(__builtin_amdgcn_readlane(take, 0), __builtin_amdgcn_readlane(take, 16)),
-                             max(__builtin_amdgcn_readlane(take, 32), __builtin_amdgcn_readlane(take, 48)));
-                // (blocks of eight steps with the second half's LDS reads issued ahead of the first half's FMAs were
-                //  tried: no gain)
-                // The LDS-read / FMA blocks run at raised wave priority: a wave that has its operands selected gets the
-                // issue slots ahead of the waves still doing bookkeeping (step 0.2864 -> 0.2781 ms and 0.2690 -> 0.2563 ms on
-                // two boxes; priority 1, 2 or 3 alike; raised during the selection instead, on the loader waves, or on
-                // all consumers with the blocks one level higher: nothing)
-                asm volatile("s_setprio 1" ::: "memory");
-                {
-                    const unsigned co = coA;
-                    const double gv = gvA;
-                    if (mx > 0) { SBLAS_QSTEP4(0, 1, 2, 3); }
-                    if (mx > 4) { SBLAS_QSTEP4(4, 5, 6, 7); }
-                    if (mx > 8) { SBLAS_QSTEP4(8, 9, 10, 11); }
-                    if (mx > 12) { SBLAS_QSTEP4(12, 13, 14, 15); }
-                }
-                if (mx > 16) {
-                    const unsigned co = coB;
-                    const double gv = gvB;
-                    SBLAS_QSTEP4(0, 1, 2, 3);
-                    if (mx > 20) { SBLAS_QSTEP4(4, 5, 6, 7); }
-                    if (mx > 24) { SBLAS_QSTEP4(8, 9, 10, 11); }
-                    if (mx > 28) { SBLAS_QSTEP4(12, 13, 14, 15); }
-                }
-                asm volatile("s_setprio 0" ::: "memory");
-                cur[g] += take;
-                // a row that used its whole window and has more: fetch the next windows now and go again (rare:
-                // more than 32 nonzeros of a row inside one 128-column tile)
-                const bool more = take >= 32 && cur[g] < end[g];
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(more) == 0ull, 1)) break;
-                window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
-                window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]); // drains the queue: later counted waits stay correct
+        auto half = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            const int cbuf = step & 1;
+            // next (tile, half) (that buffer was last read before the previous barrier)
+            if (loader) {
+                if (h + 1 < NH) dma_part(t, h + 1, cbuf ^ 1);
+                else if (t < t_hi) dma_part(t + 1, 0, cbuf ^ 1);
             }
-            // next tile's windows, into the registers this super-visit is done with
-            window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+            const unsigned tile_base = (unsigned)(uintptr_t)(smem + cbuf * W2_TILE);
+            const unsigned lb = tile_base + (unsigned)k * 16u;
+            const unsigned zero_rel = (unsigned)(uintptr_t)zero_row - tile_base;
+            auto visit = [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                // younger than this group's windows: NH = 1: the other groups' windows (4 each: every visit ends with
+                // a fetch); NH = 2: the windows of the groups behind this one (the fetches of a tile are issued in its
+                // last half, in group order)
+                if (h == 0) window_wait6<NH == 1 ? 4 * (G - 1) : 4 * (G - 1 - g)>(wca[g], wva[g], wcb[g], wvb[g]);
+                else if (replay[g]) window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]);
+                double &q0 = acc[h][g][0], &q1 = acc[h][g][1], &q2 = acc[h][g][2], &q3 = acc[h][g][3];
+                int lc = cur[g];
+                bool full = h == 0 || replay[g];
+                for (;;) {
+                    unsigned coA, coB;
+                    double gvA, gvB;
+                    int take, mx;
+                    if (full) {
+                        const int rem = end[g] - lc;
+                        unsigned long long mA, mB;
+                        window_select6(wca[g], wva[g], tile_lo, rem, k, zero_rel, coA, gvA, mA);
+                        window_select6(wcb[g], wvb[g], tile_lo, rem - 16, k, zero_rel, coB, gvB, mB);
+                        // entries of this tile per matrix row (= per DPP row), as a per-lane value
+                        const unsigned fa = q < 2 ? (unsigned)mA : (unsigned)(mA >> 32);
+                        const unsigned fb = q < 2 ? (unsigned)mB : (unsigned)(mB >> 32);
+                        const int sh = (q & 1) * 16;
+                        take = __popc((fa >> sh) & 0xffffu) + __popc((fb >> sh) & 0xffffu);
+                        // with ascending columns they are exactly the first `take` entries of the row's window
+                        viol |= mA ^ __builtin_amdgcn_ballot_w64(k < take);
+                        viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
+                        mx = max(max(__builtin_amdgcn_readlane(take, 0), __builtin_amdgcn_readlane(take, 16)),
+                                 max(__builtin_amdgcn_readlane(take, 32), __builtin_amdgcn_readlane(take, 48)));
+                        if (NH > 1 && h == 0) {
+                            s_coA[g] = coA, s_coB[g] = coB, s_gvA[g] = gvA, s_gvB[g] = gvB, s_take[g] = take, s_mx[g] = mx;
+                        }
+                    } else {
+                        coA = s_coA[g], coB = s_coB[g], gvA = s_gvA[g], gvB = s_gvB[g], take = s_take[g], mx = s_mx[g];
+                    }
+                    // (blocks of eight steps with the second half's LDS reads issued ahead of the first half's FMAs were
+                    //  tried: no gain)
+                    // The LDS-read / FMA blocks run at raised wave priority: a wave that has its operands selected gets the
+                    // issue slots ahead of the waves still doing bookkeeping (step 0.2864 -> 0.2781 ms and 0.2690 -> 0.2563 ms on
+                    // two boxes; priority 1, 2 or 3 alike; raised during the selection instead, on the loader waves, or on
+                    // all consumers with the blocks one level higher: nothing)
+                    asm volatile("s_setprio 1" ::: "memory");
+                    {
+                        const unsigned co = coA;
+                        const double gv = gvA;
+                        if (mx > 0) { SBLAS_QSTEP4(0, 1, 2, 3); }
+                        if (mx > 4) { SBLAS_QSTEP4(4, 5, 6, 7); }
+                        if (mx > 8) { SBLAS_QSTEP4(8, 9, 10, 11); }
+                        if (mx > 12) { SBLAS_QSTEP4(12, 13, 14, 15); }
+                    }
+                    if (mx > 16) {
+                        const unsigned co = coB;
+                        const double gv = gvB;
+                        SBLAS_QSTEP4(0, 1, 2, 3);
+                        if (mx > 20) { SBLAS_QSTEP4(4, 5, 6, 7); }
+                        if (mx > 24) { SBLAS_QSTEP4(8, 9, 10, 11); }
+                        if (mx > 28) { SBLAS_QSTEP4(12, 13, 14, 15); }
+                    }
+                    asm volatile("s_setprio 0" ::: "memory");
+                    lc += take;
+                    // a row that used its whole window and has more: fetch the next windows now and go again (rare:
+                    // more than 32 nonzeros of a row inside one 128-column tile)
+                    const bool more = take >= 32 && lc < end[g];
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(more) == 0ull, 1)) break;
+                    if (NH > 1 && h == 0) replay[g] = true;
+                    window_issue6(rc, rv, lc + k, wca[g], wva[g], wcb[g], wvb[g]);
+                    window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]); // drains the queue: later counted waits stay correct
+                    full = true;
+                }
+                if (h == NH - 1) {
+                    cur[g] = lc;
+                    if (NH > 1) replay[g] = false;
+                    // next tile's windows, into the registers this super-visit is done with
+                    window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+                } else if (replay[g]) {
+                    // several rounds: the second half starts from the tile's first windows again
+                    window_issue6(rc, rv, cur[g] + k, wca[g], wva[g], wcb[g], wvb[g]);
+                }
+            };
+            if (active) {
+                visit(std::integral_constant<int, 0>{});
+                visit(std::integral_constant<int, 1>{});
+                if constexpr (G > 2) visit(std::integral_constant<int, 2>{});
+            }
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory"); // the tile has landed
+            __syncthreads(); // E_t
+            ++step;
         };
-        if (active) {
-            visit(std::integral_constant<int, 0>{});
-            visit(std::integral_constant<int, 1>{});
-            if constexpr (G > 2) visit(std::integral_constant<int, 2>{});
-        }
-        if (loader) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dummy)::"memory"); // the tile has landed
-        __syncthreads(); // E_t
+        half(std::integral_constant<int, 0>{});
+        if constexpr (NH > 1) half(std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) window_wait6<0>(wca[g], wva[g], wcb[g], wvb[g]); // retire the unused last fetches
@@ -940,51 +995,57 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     if (bad && lane == 0) atomicOr(&sm_i[0], 1);
     __syncthreads(); // V
     const bool fell_back = sm_i[0] != 0;
-    if (fell_back) {
-        // recompute straight from L2, one column per lane: acc[g][j] <- row 4g+j of the wave
-        const unsigned lane_off = (unsigned)(col0 + lane);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rr = wave * RW + 4 * g + j;
-                const int row = row0 + rr;
-                int a = 0, b = 0;
-                if (rr < panel_rows && row < rows) {
-                    a = wave_uniform(rowptr[row]);
-                    b = wave_uniform(rowptr[row + 1]);
-                }
-                acc[g][j] = row_direct(colidx, val, Bt, ld32, lane_off, lane, a, b);
-            }
-    }
     if (tid == 0 && blockIdx.y == 0) atomicAdd(&g_panel_stats[fell_back ? 2 : 0], 1ull);
 
-    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows
+    // park the panel as [column][row] in the (now dead) tile buffers and write it back along rows, one 64-column half
+    // at a time
     double *ctile = smem;
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (fell_back) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ctile[lane * (RMAX + 1) + wave * RW + 4 * g + j] = acc[g][j];
-        } else {
-            const int rr = wave * RW + 4 * g + q;
-            ctile[(2 * k) * (RMAX + 1) + rr] = acc[g][0];
-            ctile[(2 * k + 1) * (RMAX + 1) + rr] = acc[g][1];
-            ctile[(32 + 2 * k) * (RMAX + 1) + rr] = acc[g][2];
-            ctile[(33 + 2 * k) * (RMAX + 1) + rr] = acc[g][3];
-        }
-    }
-    __syncthreads(); // F
     const int nrows = min(panel_rows, rows - row0);
-    const int ncols = min(64, n - col0);
-    // (fetching the old C values in the prologue, to take their HBM latency out of the epilogue, did not pay: the
-    //  registers they hold across the tile loop spill)
-    for (int idx = tid; idx < 64 * panel_rows; idx += 1024) {
-        const int r = idx % panel_rows, j = idx / panel_rows;
-        if (r < nrows && j < ncols) {
-            double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
-            const double sres = alpha * ctile[j * (RMAX + 1) + r];
-            *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int colh = col0 + 64 * h;
+        if (fell_back) {
+            // recompute straight from L2, one column per lane: acc[h][g][j] <- row 4g+j of the wave
+            const unsigned lane_off = (unsigned)(colh + lane);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = wave * RW + 4 * g + j;
+                    const int row = row0 + rr;
+                    int a = 0, b = 0;
+                    if (rr < panel_rows && row < rows) {
+                        a = wave_uniform(rowptr[row]);
+                        b = wave_uniform(rowptr[row + 1]);
+                    }
+                    acc[h][g][j] = row_direct(colidx, val, Bt, ld32, lane_off, lane, a, b);
+                }
+        }
+        if (h > 0) __syncthreads(); // the previous half has been written back
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (fell_back) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ctile[lane * (RMAX + 1) + wave * RW + 4 * g + j] = acc[h][g][j];
+            } else {
+                const int rr = wave * RW + 4 * g + q;
+                ctile[(2 * k) * (RMAX + 1) + rr] = acc[h][g][0];
+                ctile[(2 * k + 1) * (RMAX + 1) + rr] = acc[h][g][1];
+                ctile[(32 + 2 * k) * (RMAX + 1) + rr] = acc[h][g][2];
+                ctile[(33 + 2 * k) * (RMAX + 1) + rr] = acc[h][g][3];
+            }
+        }
+        __syncthreads(); // F
+        const int ncols = min(64, n - colh);
+        // (fetching the old C values in the prologue, to take their HBM latency out of the epilogue, did not pay: the
+        //  registers they hold across the tile loop spill)
+        for (int idx = tid; idx < 64 * panel_rows; idx += 1024) {
+            const int r = idx % panel_rows, j = idx / panel_rows;
+            if (r < nrows && j < ncols) {
+                double *dst = C + (int64_t)(colh + j) * ldc + (row0 + r);
+                const double sres = alpha * ctile[j * (RMAX + 1) + r];
+                *dst = (beta == 0.0) ? sres : fma(beta, *dst, sres);
+            }
         }
     }
 }
@@ -2129,13 +2190,13 @@ void raise_dynamic_lds(const void *fn, size_t bytes)
 
 // Sixth generation, one workgroup per CU at a time: the groups per wave (2 or 3) and the panel height (a multiple of
 // the rows of a wave) that minimise rounds x (height + per-tile fixed cost).
-static void gen6_plan(int rows, int &info_rows, int &gen6_g)
+static void gen6_plan(int rows, int &info_rows, int &gen6_g, int gmax = W6_GMAX)
 {
     const int ncu = compute_units();
     int best = 128;
     long best_cost = -1;
     gen6_g = 2;
-    for (int g = 2; g <= W6_GMAX; ++g)
+    for (int g = 2; g <= gmax; ++g)
         for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
             const long panels = (rows + r - 1) / r;
             // measured on the bench matrix: three groups per wave cost ~15 % more per row
@@ -2150,7 +2211,7 @@ static void gen6_plan(int rows, int &info_rows, int &gen6_g)
     const Options &opt = options();
     if (opt.panel_rows > 0) { /* experiments */
         const int r = opt.panel_rows, g = opt.panel_groups ? opt.panel_groups : (r % 12 == 0 && r > 128 ? 3 : 2);
-        if ((g == 2 || g == 3) && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) { // (workspace: a verdict per 32 rows)
+        if (g >= 2 && g <= gmax && r >= SPMM_MIN_PANEL_ROWS && r <= 48 * g && r % (4 * g) == 0) { // (workspace: a verdict per 32 rows)
             info_rows = r;
             gen6_g = g;
         }
@@ -2191,7 +2252,8 @@ static void lanes_plan(int rows, int ldbt, int &info_rows, int &groups)
 static void panel_plan(int rows, int64_t ldbt, int &info_rows, int &groups)
 {
     if (ldbt < 64) lanes_plan(rows, (int)ldbt, info_rows, groups);
-    else gen6_plan(rows, info_rows, groups);
+    // (128+ staged columns: two column halves per workgroup, whose accumulators leave room for two groups per wave)
+    else gen6_plan(rows, info_rows, groups, (ldbt >= 128 && options().tune[1] != 1) ? 2 : W6_GMAX);
 }
 
 static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts and one staging pass (see classify_panel)
@@ -2340,7 +2402,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             // 1. classify row panels; 2. LDS-tiled kernel and matrix-core kernel on the panels that qualify;
             // 3. direct kernel on the rest
             int gen6_g = 2;
-            gen6_plan(rows, info_rows, gen6_g);
+            panel_plan(rows, ldbt, info_rows, gen6_g);
             const int np = (rows + info_rows - 1) / info_rows;
             if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
@@ -2354,18 +2416,24 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             if (ldbt >= 128)
                 hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(1024), 0, s, np, t.hdr, t.info, t.cls, epoch,
                                    variant == SPMM_VARIANT_MFMA ? 1 : 0);
-            dim3 wgrid((unsigned)np, (unsigned)(ldbt / 64));
+            // 128+ staged columns: two 64-column halves per workgroup, the selection work of a (rows, tile) visit shared
+            // (SBLAS_TUNE=*,1 keeps one half per workgroup: A/B runs)
+            const bool two_halves = ldbt >= 128 && opt.tune[1] != 1;
+            dim3 wgrid((unsigned)np, (unsigned)(ldbt / (two_halves ? 128 : 64)));
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
+#define SBLAS_LAUNCH_W6(GG, NH)                                                                                        \
+    do {                                                                                                              \
+        raise_dynamic_lds((const void *)spmm_window6_kernel<GG, NH>, W2_LDS_BYTES);                                   \
+        hipLaunchKernelGGL((spmm_window6_kernel<GG, NH>), wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,   \
+                           colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz); \
+    } while (0)
             if (gen6_g == 3) {
-                raise_dynamic_lds((const void *)spmm_window6_kernel<3>, W2_LDS_BYTES);
-                hipLaunchKernelGGL(spmm_window6_kernel<3>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz);
+                SBLAS_LAUNCH_W6(3, 1);
             } else {
-                raise_dynamic_lds((const void *)spmm_window6_kernel<2>, W2_LDS_BYTES);
-                hipLaunchKernelGGL(spmm_window6_kernel<2>, wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,
-                                   colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz);
+                if (two_halves) SBLAS_LAUNCH_W6(2, 2); else SBLAS_LAUNCH_W6(2, 1);
             }
+#undef SBLAS_LAUNCH_W6
             if (kev) {
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;
