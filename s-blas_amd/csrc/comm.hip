@@ -5,6 +5,7 @@
 // Replaces spmm.h:179-181,189,260-262,279 and spmv.h:43-45,58,115-118,134.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -40,10 +41,13 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // SBLAS_RCCL_LIB: another library with the same seven entry points (tests/rccl_stub: lets the exchange branches
+        // below execute on a one-GPU box; never set in production)
+        const char *over = getenv("SBLAS_RCCL_LIB");
+        const char *names[] = {over && *over ? over : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
             r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
+            if (r.handle || (over && *over)) break; // (an override that does not load is an error, not a fallback)
         }
         if (!r.handle) return;
         r.CommInitAll = (fn_CommInitAll)dlsym(r.handle, "ncclCommInitAll");
@@ -75,6 +79,12 @@ extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
     if (n_gpu <= 0 || n_gpu > sblas::MAX_REPLICAS || !comm_out) return SBLAS_E_INVALID;
     std::vector<int> key(n_gpu);
     for (int i = 0; i < n_gpu; ++i) key[i] = devs ? devs[i] : i;
+    // TEST SWITCH (with SBLAS_RCCL_LIB = the stub of tests/rccl_stub): ranks that share a device take the exchange
+    // path -- communicator, grouped send / recv, grouped all-reduce -- instead of the one-device fold.  A real RCCL
+    // rejects duplicate devices in ncclCommInitAll, so the switch does nothing useful outside the tests.
+    const char *fe = getenv("SBLAS_COMM_FORCE_EXCHANGE");
+    const bool force_exchange = fe && *fe && *fe != '0';
+    if (force_exchange) key.push_back(-1); // (a cache entry of its own)
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_sets.find(key);
     if (it != g_sets.end()) {
@@ -82,7 +92,7 @@ extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
         return SBLAS_OK;
     }
     auto set = std::make_unique<CommSet>();
-    set->devs = key;
+    set->devs.assign(key.begin(), key.begin() + n_gpu);
     bool all_same = true, all_distinct = true;
     for (int i = 0; i < n_gpu; ++i)
         for (int j = i + 1; j < n_gpu; ++j) {
@@ -94,7 +104,7 @@ extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
     int rc = SBLAS_OK;
     if (n_gpu == 1) {
         // a single rank: the sum over ranks is the identity, no communicator needed
-    } else if (all_same) {
+    } else if (all_same && !force_exchange) {
         set->one_device = true;
         if (hipSetDevice(key[0]) != hipSuccess) rc = SBLAS_E_HIP;
         for (int i = 0; i < n_gpu && rc == SBLAS_OK; ++i) {
@@ -102,12 +112,12 @@ extern "C" int sblas_hip_comm_get(int n_gpu, const int *devs, void **comm_out)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = SBLAS_E_HIP;
             else set->events.push_back(e);
         }
-    } else if (all_distinct) {
+    } else if (all_distinct || force_exchange) {
         Rccl &r = rccl();
         if (!r.ok) rc = SBLAS_E_RCCL;
         if (rc == SBLAS_OK) {
             set->comms.assign(n_gpu, nullptr);
-            if (r.CommInitAll(set->comms.data(), n_gpu, key.data()) != 0) {
+            if (r.CommInitAll(set->comms.data(), n_gpu, set->devs.data()) != 0) {
                 set->comms.clear();
                 rc = SBLAS_E_RCCL;
             }

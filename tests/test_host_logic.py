@@ -208,7 +208,7 @@ def test_argument_validation_returns_codes_without_a_gpu(sblas):
     assert L.sblas_hip_axpby_f64(-1, None, -5, 1.0, one, 1.0, one) == 1
     assert L.sblas_hip_spmm_ldbt(64) == 64 and L.sblas_hip_spmm_ldbt(65) == 128 and L.sblas_hip_spmm_ldbt(8) == 8
     assert L.sblas_hip_spmm_ldbt(33) == 64 and L.sblas_hip_spmm_ldbt(129) == 256
-    assert L.sblas_hip_spmm_ldbt(9) == 64 and L.sblas_hip_spmm_ldbt(32) == 64     # 9..32 columns use the 64-column kernels
+    assert L.sblas_hip_spmm_ldbt(9) == 16 and L.sblas_hip_spmm_ldbt(16) == 16 and L.sblas_hip_spmm_ldbt(17) == 32 and L.sblas_hip_spmm_ldbt(32) == 32   # the widths method 1 hands a GPU at N = 64
     assert L.sblas_hip_spmm_csr_f64_i32_workspace(10, 100, 5, 64) == 101 * 64 * 8 + 96 + 8192   # Bt + zero row; tail: 16 header ints, 1024 column-range pairs, one span + one class per panel, rounded to 16 bytes
     assert b"workspace" in L.sblas_hip_error_string(3)
     # Queen_4147-sized B at N = 256 (8.5 GB row-major) is walked in 128-column chunks: workspace = one chunk
