@@ -5,7 +5,7 @@
 //   stage_classify_kernel        stage 1 + classify_panels_kernel in one launch (fused C-ABI entry)
 //   classify_panels_kernel       per row panel: column span and class (LDS-tiled / direct / matrix cores), shared-rows flag
 //   mfma_vote_kernel             one workgroup: matrix-wide decisions before stage 2 (128+ staged columns)
-//   spmm_window6_kernel<G>       qualifying panels: 128-row x 64-column B tiles through LDS (LDS-DMA loader waves),
+//   spmm_window6_kernel<G, NH>   qualifying panels: 152-row x 64-column B tiles through LDS (LDS-DMA loader waves),
 //                                one DPP row per matrix row, streaming windows of A
 //   spmm_direct_dpp_kernel<GROUPS> all other panels: a row per wave, Bt rows straight from L2, DPP broadcast
 //   spmm_direct_merge_kernel     ... of matrices whose neighbouring rows share column patterns (multi-dof FEM, 128-column
@@ -294,7 +294,14 @@ __device__ __forceinline__ double row_direct(const int *__restrict__ colidx, con
     }
     return acc;
 }
-constexpr int W2_ROWS = 128;              // Bt rows per LDS tile
+#ifndef SBLAS_W2_ROWS
+#define SBLAS_W2_ROWS 152
+#endif
+// 152 rows: two tiles fill the 160 KiB of LDS (128-row tiles: 0.266 ms per step on the bench matrix, 144: 0.252, 152: 0.248 --
+// fewer (rows, tile) visits, fuller 4-step blocks; gpurun_out/r3_ab_tile.txt)
+constexpr int W2_ROWS = SBLAS_W2_ROWS;    // Bt rows per LDS tile (a multiple of 8: four loader waves, two rows per DMA instruction)
+constexpr int W2_LROWS = W2_ROWS / 4;     // ... per loader wave
+static_assert(W2_ROWS % 8 == 0, "tile rows");
 constexpr int W2_TILE = W2_ROWS * 64;     // doubles
 constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64 * sizeof(int);
 
@@ -724,7 +731,7 @@ __device__ __forceinline__ void window_select6(int wc, double wv, int tile_lo, i
     int glo, ghi;
     asm volatile("v_subrev_u32 %[co], %[tlo], %[wc]\n\t"
                  "v_cmp_gt_i32 %[m], %[rem], %[k]\n\t"
-                 "v_cmp_gt_u32 vcc, 0x80, %[co]\n\t"
+                 "v_cmp_gt_u32 vcc, %[tr], %[co]\n\t"
                  "v_lshlrev_b32 %[co], 9, %[co]\n\t"
                  "s_and_b64 vcc, vcc, %[m]\n\t"
                  "s_mov_b64 %[m], vcc\n\t"
@@ -733,7 +740,7 @@ __device__ __forceinline__ void window_select6(int wc, double wv, int tile_lo, i
                  "v_cndmask_b32 %[ghi], 0, %[vhi], vcc"
                  : [co] "=&v"(co), [m] "=&s"(m), [glo] "=&v"(glo), [ghi] "=&v"(ghi)
                  : [tlo] "s"(tile_lo), [wc] "v"(wc), [rem] "v"(rem), [k] "v"(k), [zr] "v"(zero_rel),
-                   [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv))
+                   [vlo] "v"(__double2loint(wv)), [vhi] "v"(__double2hiint(wv)), [tr] "n"(W2_ROWS)
                  : "vcc", "scc");
     gv = __hiloint2double(ghi, glo);
 }
@@ -825,14 +832,16 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
     // tile t, column half h -> buffer buf
     auto dma_part = [&](int t, int h, int buf) {
         const int lw = wave - 12;
-        const int r0 = t * W2_ROWS + lw * 32;
-        const unsigned lds0 = (unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)lw * 16384u;
+        const int r0 = t * W2_ROWS + lw * W2_LROWS;
+        const unsigned lds0 = (unsigned)wave_uniform((int)((unsigned)(uintptr_t)(smem + buf * W2_TILE) + (unsigned)lw * (unsigned)(W2_LROWS * 512)));
         const unsigned hoff = (unsigned)h * 512u;
-        if (r0 + 31 <= cols) {
+        if (r0 + W2_LROWS - 1 <= cols) {
             const char *p = bt_bytes + (size_t)((unsigned)r0 * ldb8) + hoff;
-            for (int i = 0; i < 16; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
+#pragma unroll
+            for (int i = 0; i < W2_LROWS / 2; ++i) dma_rows_scalar(lds0 + i * 1024u, pair_off, p + (size_t)(2u * i) * ldb8);
         } else {
-            for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int i = 0; i < W2_LROWS / 2; ++i) {
                 const unsigned brow = (unsigned)min(r0 + 2 * i + (lane >> 5), cols);
                 dma_rows_vector(lds0 + i * 1024u, bt_bytes + (size_t)(brow * ldb8 + piece_off + hoff));
             }

@@ -1,0 +1,12 @@
+# A/B of library builds on one box: tools/r3_ab.sh <ncols> lib1 lib2 ... (files under gpurun_ab/), two interleaved rounds
+cd $GRAFT_REPO_ROOT
+n=$1; shift
+cp s-blas_amd/lib/libsblas_hip.so /tmp/orig.so
+for round in 1 2; do for l in "$@"; do
+  cp gpurun_ab/$l s-blas_amd/lib/libsblas_hip.so
+  python bench.py --ncols $n --no-extras --cpu-seconds 0 --steps 100 > /tmp/ab.json 2> /tmp/ab.err || { tail -5 /tmp/ab.err; cp /tmp/orig.so s-blas_amd/lib/libsblas_hip.so; exit 1; }
+  python - <<PY
+import json;d=json.loads(open('/tmp/ab.json').read().strip().splitlines()[-1]);print('$l', $n, d['ms_per_step'], d['roofline']['kernel_ms'], d['oracle_check'])
+PY
+done; done
+cp /tmp/orig.so s-blas_amd/lib/libsblas_hip.so
