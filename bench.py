@@ -292,12 +292,27 @@ def secondary_queen(args, torch, S, dev, rows=300000, n=256, steps=10):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        ok, err = check_windows(O, C.view(n, m), m, m, n, rp, ci, v, Bh, 3 + steps, (0, m // 2, m - 64))
+        # the same step through a per-matrix plan (sblas_hip_spmm_plan_*: classified once, only the kernels with panels)
+        plan = S.SpmmPlan(m, m, rowptr, colidx, n)
+        pstep = lambda: plan.spmm(val, B, m, n, 1.0, 1.0, C, m, ws)
+        for _ in range(3):
+            pstep()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            pstep()
+        e1.record()
+        torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1) / steps
+        pinfo = plan.info()
+        plan.destroy()
+        ok, err = check_windows(O, C.view(n, m), m, m, n, rp, ci, v, Bh, 2 * (3 + steps), (0, m // 2, m - 64))
         alg = algorithmic_bytes(m, m, nnz, n, True)
         kernel = dominant_kernel_name(S, n, census)
         traffic, src = measured_traffic(kernel, m, nnz, n)
         out[key] = {"workload": "Queen_4147-like (%s), %d rows, %d nnz, N=%d, alpha=beta=1" % (key, m, nnz, n),
                     "ms_per_step": round(ms, 5), "gflops": round(2.0 * nnz * n / ms / 1e6, 1), "panels": census,
+                    "planned_ms_per_step": round(pms, 5), "plan": pinfo,
                     "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic,
                                  "traffic_source": src, "algorithmic_bytes_per_launch": alg,
@@ -322,9 +337,23 @@ def secondary_queen(args, torch, S, dev, rows=300000, n=256, steps=10):
             e1.record()
             torch.cuda.synchronize()
             bms = e0.elapsed_time(e1) / steps
-            bok, berr = check_windows(O, Cb.view(n, mi), mi, m, n, sub_rp, sub_ci, sub_v, Bh, 3 + steps, (0, mi // 2, mi - 64))
+            bci, bval = colidx[rp[a]:rp[b]].contiguous(), val[rp[a]:rp[b]].contiguous()
+            bplan = S.SpmmPlan(mi, m, srp, bci, n)
+            bpstep = lambda: bplan.spmm(bval, B, m, n, 1.0, 1.0, Cb, mi, ws)
+            for _ in range(3):
+                bpstep()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                bpstep()
+            e1.record()
+            torch.cuda.synchronize()
+            bpms = e0.elapsed_time(e1) / steps
+            bpinfo = bplan.info()
+            bplan.destroy()
+            bok, berr = check_windows(O, Cb.view(n, mi), mi, m, n, sub_rp, sub_ci, sub_v, Bh, 2 * (3 + steps), (0, mi // 2, mi - 64))
             out[key]["method2_rank_share"] = {"block": "3 of 8 by nonzeros: rows [%d, %d)" % (a, b), "nnz": int(len(sub_ci)),
-                                              "ms_per_step": round(bms, 5),
+                                              "ms_per_step": round(bms, 5), "planned_ms_per_step": round(bpms, 5), "plan": bpinfo,
                                               "gflops": round(2.0 * len(sub_ci) * n / bms / 1e6, 1),
                                               "oracle_check": bok, "oracle_max_abs_diff": berr}
             del srp, Cb
@@ -616,6 +645,28 @@ def main():
     t_stage1 = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     s2 = [e[1].elapsed_time(e[2]) for e in ev]
     t_stage2 = float(np.mean(s2)) * 1e-3
+    # the same step through a per-matrix plan (informational: `value` is the unplanned call, the drop-in boundary as a
+    # caller that knows nothing of plans uses it)
+    planned = None
+    try:
+        t_c0 = time.perf_counter()
+        plan = S.SpmmPlan(rows, cols, rowptr, colidx, n)
+        torch.cuda.synchronize()
+        create_ms = (time.perf_counter() - t_c0) * 1e3
+        for _ in range(10):
+            plan.spmm(val, B, cols, n, 1.0, 1.0, C, rows, Bt)
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.spmm(val, B, cols, n, 1.0, 1.0, C, rows, Bt)
+        torch.cuda.synchronize()
+        planned = {"ms_per_step": round((time.perf_counter() - p0) / args.steps * 1e3, 5), "plan_create_ms": round(create_ms, 3),
+                   "plan": plan.info(), "note": "sblas_hip_spmm_csr_f64_i32_planned: panels classified once, only the kernels with "
+                                                "panels launched; same results bit for bit"}
+        extra_steps += 10 + args.steps
+        plan.destroy()
+    except S.SblasError as ex:
+        planned = {"error": repr(ex)}
     kernel = dominant_kernel_name(S, n, census)
     if not (kernel.startswith("spmm_window6") or kernel.startswith("spmm_lanes")):
         t_dom = None                                 # the launcher's events bracket the LDS-tiled kernels only
@@ -660,6 +711,7 @@ def main():
                      "staging_kernel_ms": round(t_stage1 * 1e3, 5),
                      "kernel_gflops": round(flops_step / t_roof / 1e9, 1), "panels": census},
         "hbm_gbs_whole_step": round(alg / (elapsed / args.steps) / 1e9, 1),
+        "planned": planned,
         "cold_ms_per_step": round(cold_ms, 5),      # first ten steps of the process, idle clocks, host wall incl. launches
         "oracle_check": check, "oracle_max_abs_diff": check_err,
     }

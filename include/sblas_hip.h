@@ -78,6 +78,29 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream,
                                          const double *Bt, int64_t ldbt, int64_t n,
                                          double alpha, double beta, double *C, int64_t ldc);
 
+/* A per-matrix plan -- the slot cusparseSpMM_bufferSize / the workspace step occupy in the reference (spmm.h:134-141).
+ * The unplanned call classifies A's row panels on the device on EVERY call (which stage-2 kernel computes a panel, the
+ * matrix-wide votes, a row block's column range) and then launches every stage-2 kernel; those that find nothing to do
+ * leave at once.  A is usually multiplied many times: sblas_hip_spmm_plan_create runs that analysis once for one
+ * structure (rowptr, colidx) and one width n, keeps the verdicts in a device buffer of its own and looks at them once
+ * on the host (it synchronises `stream`); a planned call then stages B and launches ONLY the kernels that have panels.
+ * Results are bit-identical to the unplanned call.  The plan refers to the structure arrays it was made from: the
+ * caller recreates it when their contents change (values may change freely).  One call at a time per plan (the
+ * staging pass keeps its "B holds a non-finite value" flag in the plan's buffer).  A planned call allocates nothing
+ * and never synchronises (graph-capturable); create / destroy do. */
+int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, int64_t n, void **plan_out);
+int sblas_hip_spmm_plan_destroy(void *plan);
+/* out: [0] planned at all (0: empty matrix or a pinned kernel selection -- calls run unplanned), panels for the
+ * LDS-tiled [1] / direct [2] / matrix-core [3] kernels, [4] direct panels go to the row-merging kernel, [5] only the
+ * block's column range of B is staged, [6] staged width, [7] rows per panel */
+int sblas_hip_spmm_plan_info(const void *plan, int64_t out[8]);
+int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream,
+                                       int64_t rows, int64_t cols, int64_t nnz,
+                                       const int32_t *rowptr, const int32_t *colidx, const double *val,
+                                       const double *B, int64_t ldb, int64_t n, double alpha, double beta,
+                                       double *C, int64_t ldc, void *workspace, size_t workspace_bytes);
+
 /* Diagnostics (synchronises the current device): how many row panels of the SpMM launches since the last reset
  * took the LDS-windowed path [0], the direct path because they are too sparse over their column span [1], or were
  * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2], or the matrix-core

@@ -101,6 +101,14 @@ static bool ldbt_ok(int64_t ldbt, int64_t n)
 // (Queen_4147 with N = 256: two chunks of 128).  SBLAS_SPMM_MAX_BT_BYTES lowers the limit (tests).
 static uint64_t bt_byte_limit() { return sblas::options().max_bt_bytes; }
 
+// Staging traffic saved if a row block's columns span no more than twice its rows, against the extra pass over the column
+// indices and one more launch (~5 us = 40 MB at staging speed; a quarter of nd24k at N = 128 breaks even, an eighth of a
+// Queen-like matrix at N = 256 runs 1.5x faster: tools/spmm_shapes.py --block)
+static bool range_staging_pays(int64_t rows, int64_t cols, int64_t nnz, int64_t ldbt)
+{
+    return cols > 2 * rows && (uint64_t)(cols - 2 * rows) * (uint64_t)ldbt * 16ull > (uint64_t)nnz * 8ull + (40ull << 20);
+}
+
 static int64_t spmm_chunk_cols(int64_t cols, int64_t n)
 {
     const uint64_t lim = bt_byte_limit();
@@ -181,10 +189,19 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     return spmm_staged(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, 0);
 }
 
-int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
-                               const int32_t *rowptr, const int32_t *colidx, const double *val,
-                               const double *B, int64_t ldb, int64_t n, double alpha, double beta,
-                               double *C, int64_t ldc, void *workspace, size_t workspace_bytes)
+// A plan: the panel verdicts of one matrix structure at one staged width, taken once (sblas_hip_spmm_plan_create).
+struct SpmmPlan {
+    int dev = -1;
+    int64_t rows = 0, cols = 0, nnz = 0, n = 0, ldbt = 0;
+    const void *rowptr = nullptr, *colidx = nullptr;
+    bool active = false;      // false: nothing to plan (empty matrix, a pinned direct variant): calls run unplanned
+    void *buf = nullptr;
+    sblas::PlanView pv;
+};
+
+static int spmm_impl(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                     const int32_t *colidx, const double *val, const double *B, int64_t ldb, int64_t n, double alpha,
+                     double beta, double *C, int64_t ldc, void *workspace, size_t workspace_bytes, const SpmmPlan *plan)
 {
     if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val) || n < 0) return SBLAS_E_INVALID;
     if (rows == 0 || n == 0) return SBLAS_OK;
@@ -205,7 +222,19 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
         // Staging traffic saved if the block's columns span no more than twice its rows, against the extra pass over the
         // column indices and one more launch (~5 us = 40 MB at staging speed; a quarter of nd24k at N = 128 breaks even,
         // an eighth of a Queen-like matrix at N = 256 runs 1.5x faster: tools/spmm_shapes.py --block)
-        const bool pays = cols > 2 * rows && (uint64_t)(cols - 2 * rows) * (uint64_t)ldbt * 16ull > (uint64_t)nnz * 8ull + (40ull << 20);
+        const bool pays = range_staging_pays(rows, cols, nnz, ldbt);
+        if (plan && plan->active && ldbt == plan->ldbt && ldbt_ok(ldbt, nj)) {
+            // planned: stage (no classifier rides along), then only the stage-2 kernels that have panels
+            DeviceScope scope(dev);
+            if (scope.err != hipSuccess) return SBLAS_E_HIP;
+            if ((reinterpret_cast<uintptr_t>(Bt) & 15u) != 0) return SBLAS_E_INVALID;
+            if (sblas::launch_stage_planned((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, plan->pv) != hipSuccess)
+                return SBLAS_E_HIP;
+            if (sblas::launch_spmm_rowpanel((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, val, Bt, ldbt, (int)nj,
+                                            alpha, beta, C + j0 * ldc, ldc, spmm_variant(), 0, &plan->pv) != hipSuccess)
+                return SBLAS_E_HIP;
+            continue;
+        }
         if (ldbt >= 64 && ldbt_ok(ldbt, nj) && (sr > 0 || (sr < 0 && pays))) {
             // a row block (method 2): the row-major copy covers only the rows of B the block's nonzeros refer to
             DeviceScope scope(dev);
@@ -239,6 +268,79 @@ int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
         if (rc != SBLAS_OK) return rc;
     }
     return SBLAS_OK;
+}
+
+int sblas_hip_spmm_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                               const int32_t *rowptr, const int32_t *colidx, const double *val,
+                               const double *B, int64_t ldb, int64_t n, double alpha, double beta,
+                               double *C, int64_t ldc, void *workspace, size_t workspace_bytes)
+{
+    return spmm_impl(dev, stream, rows, cols, nnz, rowptr, colidx, val, B, ldb, n, alpha, beta, C, ldc, workspace,
+                     workspace_bytes, nullptr);
+}
+
+// ---- per-matrix plan (the slot of cusparseSpMM_bufferSize / preprocess, spmm.h:134-141) --------------------------
+int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                               const int32_t *colidx, int64_t n, void **plan_out)
+{
+    if (!plan_out || !csr_args_ok(rows, cols, nnz, rowptr, colidx, reinterpret_cast<const void *>(1)) || n < 0) return SBLAS_E_INVALID;
+    SpmmPlan *p = new SpmmPlan;
+    p->dev = dev, p->rows = rows, p->cols = cols, p->nnz = nnz, p->n = n, p->rowptr = rowptr, p->colidx = colidx;
+    *plan_out = p;
+    const int v = spmm_variant();
+    const bool classified = v == sblas::SPMM_VARIANT_AUTO || v == sblas::SPMM_VARIANT_MFMA || v == sblas::SPMM_VARIANT_NO_MFMA;
+    if (rows == 0 || cols == 0 || nnz == 0 || n == 0 || !classified) return SBLAS_OK; // nothing to plan
+    const int64_t w = spmm_chunk_cols(cols, n);
+    const int64_t ldbt = chunk_ldbt(cols, n, n < w ? n : w);
+    if (ldbt < 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_OK; // 64-bit narrow kernels: unplanned
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }
+    if (hipMalloc(&p->buf, sblas::plan_tail_bytes(rows)) != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }
+    p->pv.tail = static_cast<int *>(p->buf);
+    p->ldbt = ldbt;
+    const int sr = sblas::options().stage_range;
+    const bool use_range = ldbt >= 64 && (sr > 0 || (sr < 0 && range_staging_pays(rows, cols, nnz, ldbt)));
+    if (sblas::plan_build((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, ldbt, v, use_range, &p->pv) != hipSuccess) {
+        (void)hipFree(p->buf);
+        delete p;
+        *plan_out = nullptr;
+        return SBLAS_E_HIP;
+    }
+    p->active = true;
+    return SBLAS_OK;
+}
+
+int sblas_hip_spmm_plan_destroy(void *plan)
+{
+    if (!plan) return SBLAS_OK;
+    SpmmPlan *p = static_cast<SpmmPlan *>(plan);
+    if (p->buf) {
+        DeviceScope scope(p->dev);
+        (void)hipFree(p->buf);
+    }
+    delete p;
+    return SBLAS_OK;
+}
+
+int sblas_hip_spmm_plan_info(const void *plan, int64_t out[8])
+{
+    if (!plan || !out) return SBLAS_E_INVALID;
+    const SpmmPlan *p = static_cast<const SpmmPlan *>(plan);
+    out[0] = p->active, out[1] = p->pv.n_window, out[2] = p->pv.n_direct, out[3] = p->pv.n_mfma_w + p->pv.n_mfma_d;
+    out[4] = p->pv.merge, out[5] = p->pv.use_range, out[6] = p->ldbt, out[7] = p->pv.info_rows;
+    return SBLAS_OK;
+}
+
+int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                                       const int32_t *rowptr, const int32_t *colidx, const double *val, const double *B,
+                                       int64_t ldb, int64_t n, double alpha, double beta, double *C, int64_t ldc,
+                                       void *workspace, size_t workspace_bytes)
+{
+    if (!plan) return SBLAS_E_INVALID;
+    const SpmmPlan *p = static_cast<const SpmmPlan *>(plan);
+    // the plan speaks for ONE structure: the same arrays it was made from (their contents are the caller's promise)
+    if (p->rows != rows || p->cols != cols || p->nnz != nnz || p->rowptr != rowptr || p->colidx != colidx) return SBLAS_E_INVALID;
+    return spmm_impl(dev, stream, rows, cols, nnz, rowptr, colidx, val, B, ldb, n, alpha, beta, C, ldc, workspace, workspace_bytes, p);
 }
 
 int sblas_hip_debug_reload_env(void)

@@ -65,6 +65,23 @@ const Options &options();
 void options_reload();
 void raise_dynamic_lds(const void *fn, size_t bytes);
 
+// A per-matrix plan (capi.hip: sblas_hip_spmm_plan_*): the panel verdicts of one (A, staged width) pair kept in a device
+// buffer of the plan's own (same layout as the workspace tail), and what the host learned from them once -- which
+// stage-2 kernels have panels at all, the matrix-wide votes, a row block's column range.
+struct PlanView {
+    int *tail = nullptr;        // TAIL_HDR ints + TAIL_PARTS int2 + one int2 + one int per panel (device)
+    int epoch = 0;              // the classifier epoch the verdicts carry
+    int info_rows = 0, groups = 0;
+    long n_window = 0, n_direct = 0, n_mfma_w = 0, n_mfma_d = 0; // panels per class after the votes
+    bool merge = false;         // the call's direct panels go to the row-merging kernel
+    bool use_range = false;     // stage only the column range [lo, hi] of B
+    int nparts = 0;
+};
+size_t plan_tail_bytes(int64_t rows);
+hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx, int64_t ldbt,
+                      int variant, bool use_range, PlanView *pv);
+hipError_t launch_stage_planned(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                                int64_t ldbt, const PlanView &pv);
 hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
                               int64_t ldbt, int rows, int64_t nnz, const int *rowptr, const int *colidx, int variant,
                               int classify, int *epoch_out);
@@ -72,7 +89,8 @@ hipError_t launch_dense_to_rowmajor(hipStream_t s, int64_t cols, int64_t n, cons
                                     double *Bt, int64_t ldbt);
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc, int variant, int pre_epoch = 0);
+                                double beta, double *C, int64_t ldc, int variant, int pre_epoch = 0,
+                                const PlanView *pv = nullptr);
 hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
                                  int64_t ldbt, int rows, const int *rowptr, const int *colidx, int variant,
                                  int *epoch_out);

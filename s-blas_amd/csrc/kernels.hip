@@ -2274,10 +2274,15 @@ struct Tail {
     int2 *info;
     int *cls;
 };
+static Tail tail_at(int *hdr, int rows);
 static Tail tail_of(const double *Bt, int64_t cols, int64_t ldbt, int rows)
 {
+    return tail_at(reinterpret_cast<int *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt), rows);
+}
+static Tail tail_at(int *hdr, int rows)
+{
     Tail t;
-    t.hdr = reinterpret_cast<int *>(const_cast<double *>(Bt) + (size_t)(cols + 1) * (size_t)ldbt);
+    t.hdr = hdr;
     const size_t panels = ((size_t)(rows > 0 ? rows : 0) + SPMM_MIN_PANEL_ROWS - 1) / SPMM_MIN_PANEL_ROWS;
     t.parts = reinterpret_cast<int2 *>(t.hdr + TAIL_HDR);
     t.info = t.parts + TAIL_PARTS;
@@ -2392,26 +2397,111 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-matrix plan (the slot cuSPARSE's bufferSize / preprocess step occupies, spmm.h:134-141): classify once, vote once,
+// look at the verdicts once on the host.
+// ---------------------------------------------------------------------------------------------
+size_t plan_tail_bytes(int64_t rows) { return workspace_tail_bytes(rows); }
+
+hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx, int64_t ldbt,
+                      int variant, bool use_range, PlanView *pv)
+{
+    const Options &opt = options();
+    const Tail t = tail_at(pv->tail, rows);
+    int info_rows = 0, g = 2;
+    panel_plan(rows, ldbt, info_rows, g);
+    const int np = (rows + info_rows - 1) / info_rows;
+    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    const float fill = ldbt < 64 ? 2.0f : mfma_min_fill(variant, info_rows, ldbt);
+    const int probe = (ldbt >= 128 && opt.direct_merge) ? 1 : 0;
+    hipError_t e = hipMemsetAsync(t.hdr, 0, TAIL_HDR * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 4095) / 4096, TAIL_PARTS));
+    if (use_range)
+        hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
+                           nparts, rows, cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), fill,
+                           probe, t.hdr, t.info, t.cls, epoch);
+    else
+        hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np, info_rows,
+                           rowptr, colidx, 1 << 24, window_min_density(info_rows), fill, probe, t.hdr, t.info, t.cls, epoch);
+    if (ldbt >= 128)
+        hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(1024), 0, s, np, t.hdr, t.info, t.cls, epoch,
+                           variant == SPMM_VARIANT_MFMA ? 1 : 0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // the one look the host takes
+    std::vector<int> hdr(TAIL_HDR), cls(np);
+    if ((e = hipMemcpyAsync(hdr.data(), t.hdr, TAIL_HDR * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(cls.data(), t.cls, (size_t)np * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    pv->epoch = epoch;
+    pv->info_rows = info_rows;
+    pv->groups = g;
+    pv->n_window = pv->n_direct = pv->n_mfma_w = pv->n_mfma_d = 0;
+    for (int p = 0; p < np; ++p) { // (a panel without nonzeros is PANEL_DIRECT: the direct kernel writes its beta * C)
+        const int c = cls[p] & PANEL_CLASS_MASK;
+        pv->n_window += c == PANEL_WINDOW;
+        pv->n_direct += c == PANEL_DIRECT;
+        pv->n_mfma_w += c == PANEL_MFMA_W;
+        pv->n_mfma_d += c == PANEL_MFMA_D;
+    }
+    pv->merge = ldbt >= 128 && hdr[TAIL_MERGE_EPOCH] == epoch;
+    pv->use_range = use_range;
+    pv->nparts = nparts;
+    return hipSuccess;
+}
+
+// stage 1 of a planned call: the flags "B holds a non-finite value" go to the PLAN's header (where the stage-2 kernels
+// of the call look), the copy covers the plan's column range when the plan has one
+hipError_t launch_stage_planned(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,
+                                int64_t ldbt, const PlanView &pv)
+{
+    const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
+    int *hdr = pv.tail;
+    if (pv.use_range && ldbt >= 64) {
+        const int64_t tiles = ((cols + 1 + STAGE_K - 1) / STAGE_K) * ((ldbt + 63) / 64);
+        hipLaunchKernelGGL(stage_range_kernel, dim3((unsigned)std::min<int64_t>(tiles, 2048)), dim3(256), 0, s, cols, n, B, ldb,
+                           Bt, ldbt, hdr, reinterpret_cast<const int2 *>(hdr + TAIL_HDR), pv.nparts, epoch);
+        return hipGetLastError();
+    }
+    const dim3 ngrid((unsigned)((cols + 1 + 255) / 256));
+    if (ldbt == 8)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<8>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else if (ldbt == 16)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<16>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else if (ldbt == 32)
+        hipLaunchKernelGGL(dense_to_rowmajor_narrow_kernel<32>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, hdr, epoch);
+    else
+        hipLaunchKernelGGL(dense_to_rowmajor_kernel, dim3((unsigned)((cols + 1 + STAGE_K - 1) / STAGE_K), (unsigned)((ldbt + 63) / 64)),
+                           dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, hdr, epoch);
+    return hipGetLastError();
+}
+
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
-                                double beta, double *C, int64_t ldc, int variant, int pre_epoch)
+                                double beta, double *C, int64_t ldc, int variant, int pre_epoch, const PlanView *pv)
 {
     const Options &opt = options();
     const double avg_row = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    // a planned call (pv): the verdicts sit in the plan's buffer, nothing is classified or voted on, and only the kernels
+    // that have panels are launched
+    const bool need_window = !pv || pv->n_window + pv->n_mfma_w > 0;
+    const bool need_mfma = !pv || pv->n_mfma_w + pv->n_mfma_d > 0;
+    const bool need_direct = !pv || pv->n_direct + pv->n_mfma_d > 0;
     if (ldbt >= 64) {
-        const Tail t = tail_of(Bt, cols, ldbt, rows);
+        const Tail t = pv ? tail_at(pv->tail, rows) : tail_of(Bt, cols, ldbt, rows);
         const int *cls = nullptr;
         int info_rows = 1;
         // pre_epoch != 0: launch_stage_classify has classified the panels already
-        const bool classified = variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
-                                variant != SPMM_VARIANT_DIRECT_MERGE;
-        const bool preclassified = pre_epoch != 0 && classified;
-        const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
+        const bool classified = pv || (variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
+                                       variant != SPMM_VARIANT_DIRECT_MERGE);
+        const bool preclassified = pv || (pre_epoch != 0 && classified);
+        const int epoch = pv ? pv->epoch : preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         if (classified) {
             // 1. classify row panels; 2. LDS-tiled kernel and matrix-core kernel on the panels that qualify;
             // 3. direct kernel on the rest
             int gen6_g = 2;
             panel_plan(rows, ldbt, info_rows, gen6_g);
+            if (pv) info_rows = pv->info_rows, gen6_g = pv->groups;
             const int np = (rows + info_rows - 1) / info_rows;
             if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
@@ -2422,7 +2512,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    (ldbt >= 128 && opt.direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
             // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)
-            if (ldbt >= 128)
+            if (ldbt >= 128 && !pv)
                 hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(1024), 0, s, np, t.hdr, t.info, t.cls, epoch,
                                    variant == SPMM_VARIANT_MFMA ? 1 : 0);
             // 128+ staged columns: two 64-column halves per workgroup, the selection work of a (rows, tile) visit shared
@@ -2437,7 +2527,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         hipLaunchKernelGGL((spmm_window6_kernel<GG, NH>), wgrid, dim3(1024), W2_LDS_BYTES, s, rows, cols, np, rowptr,   \
                            colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls, info_rows, (int)nnz); \
     } while (0)
-            if (gen6_g == 3) {
+            if (!need_window) {
+            } else if (gen6_g == 3) {
                 SBLAS_LAUNCH_W6(3, 1);
             } else {
                 if (two_halves) SBLAS_LAUNCH_W6(2, 2); else SBLAS_LAUNCH_W6(2, 1);
@@ -2447,7 +2538,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;
             }
-            if (mfma_possible) {
+            if (mfma_possible && need_mfma) {
                 const hipError_t e = launch_spmm_mfma(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc,
                                                       t.info, t.hdr, t.cls, info_rows, np, epoch, panel_stats_device());
                 if (e != hipSuccess) return e;
@@ -2459,7 +2550,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         // matrix at N = 128: +3 %); SBLAS_DIRECT_LDS overrides (experiments: rows in flight vs L2 reach)
         const size_t pad = opt.direct_lds >= 0 ? (size_t)opt.direct_lds : (ldbt == 64 ? 0 : 90000);
         const int interleave = opt.direct_map; // -1: by the span the classifier recorded
-        if (n > 32 && (variant == SPMM_VARIANT_DIRECT_ROWS || (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < 32.0))) {
+        if (!need_direct) {
+        } else if (n > 32 && (variant == SPMM_VARIANT_DIRECT_ROWS || (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < 32.0))) {
             // short rows: four rows per wave
             const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
             hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
@@ -2478,8 +2570,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         } else {
             // 128-column tiles.  Classified calls launch both direct kernels: the classifier's vote (device side) says
             // whether the rows share column patterns, and the kernel whose call it is not leaves on one scalar load.
-            const bool merge = variant == SPMM_VARIANT_DIRECT_MERGE || (cls != nullptr && opt.direct_merge);
-            const bool plain = variant != SPMM_VARIANT_DIRECT_MERGE;
+            const bool merge = pv ? pv->merge : variant == SPMM_VARIANT_DIRECT_MERGE || (cls != nullptr && opt.direct_merge);
+            const bool plain = pv ? !pv->merge : variant != SPMM_VARIANT_DIRECT_MERGE;
             if (merge) {
                 // rows that share their column pattern (multi-dof FEM): three rows per wave, shared Bt loads
                 const int mp = (rows + MERGE_PANEL - 1) / MERGE_PANEL;
@@ -2499,18 +2591,19 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
     } else {
         // ---- narrow dense blocks (ldbt = 8 / 16 / 32): LDS-tiled lane-per-entry kernel on the panels that qualify,
         // a direct kernel on the rest
-        const Tail t = tail_of(Bt, cols, ldbt, rows);
+        const Tail t = pv ? tail_at(pv->tail, rows) : tail_of(Bt, cols, ldbt, rows);
         // the 16- / 32-column direct kernel addresses Bt with 32-bit byte offsets
         const bool wide_offsets = ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull;
-        const bool classified = !wide_offsets && variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
-                                variant != SPMM_VARIANT_LANES;
-        const bool preclassified = pre_epoch != 0 && classified;
-        const int epoch = preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
+        const bool classified = pv || (!wide_offsets && variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
+                                       variant != SPMM_VARIANT_LANES);
+        const bool preclassified = pv || (pre_epoch != 0 && classified);
+        const int epoch = pv ? pv->epoch : preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         const int *cls = nullptr;
         int info_rows = 1;
         if (classified) {
             int g = 2;
             lanes_plan(rows, (int)ldbt, info_rows, g);
+            if (pv) info_rows = pv->info_rows, g = pv->groups;
             const int np = (rows + info_rows - 1) / info_rows;
             if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
@@ -2526,7 +2619,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                            info_rows, (int)nnz);                                                                      \
     } while (0)
             const int cp = opt.tune[0]; /* experiments: copies of a Bt row in the LDS tile */
-            if (ldbt == 8) {
+            if (!need_window) {
+            } else if (ldbt == 8) {
                 if (cp == 4) { if (g == 3) SBLAS_LAUNCH_LANES(8, 4, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 4, 2); else SBLAS_LAUNCH_LANES(8, 4, 1); }
                 else if (cp == 2) { if (g == 3) SBLAS_LAUNCH_LANES(8, 2, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 2, 2); else SBLAS_LAUNCH_LANES(8, 2, 1); }
                 else { if (g == 3) SBLAS_LAUNCH_LANES(8, 1, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 1, 2); else SBLAS_LAUNCH_LANES(8, 1, 1); }
@@ -2544,7 +2638,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             cls = t.cls;
         }
         const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
-        if (ldbt >= 16 && !wide_offsets && variant != SPMM_VARIANT_LANES) {
+        if (!need_direct) {
+        } else if (ldbt >= 16 && !wide_offsets && variant != SPMM_VARIANT_LANES) {
             // the row-per-wave kernel, four nonzeros per instruction: sixteen lanes x 16 bytes per nonzero (with 16 staged
             // columns the upper eight lanes of a DPP row read past the Bt row, into columns that are never stored)
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;

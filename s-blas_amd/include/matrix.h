@@ -266,14 +266,14 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
     CsrSparseMatrix()
         : csrRowPtr(NULL), csrColIdx(NULL), csrVal(NULL), csrRowPtr_gpu(NULL), csrColIdx_gpu(NULL),
           csrVal_gpu(NULL), nnz_gpu(NULL), starting_row_gpu(NULL), stoping_row_gpu(NULL), nnz(0), height(0),
-          width(0), n_gpu(0), policy(none)
+          width(0), n_gpu(0), policy(none), spmm_plan_gpu(NULL), spmm_plan_n(NULL)
     {
     }
     // MatrixMarket file -> host CSR (one parse of the text; rows keep file order, see sblas_mm_read_csr)
     CsrSparseMatrix(const char *filename)
         : csrRowPtr(NULL), csrColIdx(NULL), csrVal(NULL), csrRowPtr_gpu(NULL), csrColIdx_gpu(NULL),
           csrVal_gpu(NULL), nnz_gpu(NULL), starting_row_gpu(NULL), stoping_row_gpu(NULL), nnz(0), height(0),
-          width(0), n_gpu(0), policy(none)
+          width(0), n_gpu(0), policy(none), spmm_plan_gpu(NULL), spmm_plan_n(NULL)
     {
         int m = 0, n = 0, nnzA = 0, sym = 0;
         const int rc = mmio_info(&m, &n, &nnzA, &sym, filename);
@@ -299,8 +299,21 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
         }
         printf("input matrix A: ( %i, %i ) nnz = %i\n", m, n, nnzA);
     }
+    // the per-GPU SpMM plans (made by sblas_spmm_csr_v1 / _v2 on first use) describe the device copies: gone with them
+    void drop_spmm_plans()
+    {
+        if (spmm_plan_gpu) {
+            for (unsigned i = 0; i < n_gpu; ++i)
+                if (spmm_plan_gpu[i]) (void)sblas_hip_spmm_plan_destroy(spmm_plan_gpu[i]);
+            free(spmm_plan_gpu);
+            free(spmm_plan_n);
+            spmm_plan_gpu = NULL;
+            spmm_plan_n = NULL;
+        }
+    }
     ~CsrSparseMatrix()
     {
+        drop_spmm_plans();
         SAFE_FREE_HOST(csrRowPtr);
         SAFE_FREE_HOST(csrColIdx);
         SAFE_FREE_HOST(csrVal);
@@ -316,10 +329,13 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
     //            to its slice; a row cut by a boundary is shared by two GPUs (method 2, SpMV).
     void sync2gpu(unsigned _n_gpu, enum GpuSharePolicy _policy)
     {
+        drop_spmm_plans(); // (of the previous placement)
         n_gpu = _n_gpu;
         policy = _policy;
         assert(n_gpu != 0);
         assert(policy != none);
+        spmm_plan_gpu = (void **)calloc(n_gpu, sizeof(void *));
+        spmm_plan_n = (int64_t *)calloc(n_gpu, sizeof(int64_t));
         SAFE_ALOC_HOST(csrRowPtr_gpu, n_gpu * sizeof(IdxType *));
         SAFE_ALOC_HOST(csrColIdx_gpu, n_gpu * sizeof(IdxType *));
         SAFE_ALOC_HOST(csrVal_gpu, n_gpu * sizeof(DataType *));
@@ -404,6 +420,9 @@ template <typename IdxType, typename DataType> class CsrSparseMatrix {
     IdxType width;
     unsigned n_gpu;
     enum GpuSharePolicy policy;
+    // (not in the reference) per-GPU plan of the SpMM ops and the width it was made for; see spmm.h
+    void **spmm_plan_gpu;
+    int64_t *spmm_plan_n;
 };
 
 // ----------------------------------------------------------------------------------------------

@@ -69,6 +69,45 @@ inline void require_col_major(const char *who, DenseMatrix<IdxType, DataType> *p
     }
 }
 
+// One GPU's product.  <int, double> goes through a per-matrix plan (sblas_hip_spmm_plan_*: the slot cuSPARSE's
+// bufferSize / workspace step has at spmm.h:134-141) from the SECOND call for this matrix, GPU and width on (a caller
+// that multiplies once -- the reference's drivers -- pays nothing; making the plan synchronises the GPU's stream once);
+// the plan stays in the CsrSparseMatrix until its next sync2gpu, and every later call launches only the kernels that
+// have panels.  SBLAS_PLAN=0 keeps every call unplanned.
+template <typename IdxType, typename DataType>
+inline int spmm_on_gpu(CsrSparseMatrix<IdxType, DataType> *pA, unsigned i, void *stream, int vt, int it, int64_t m, int64_t K,
+                       int64_t nnz, const DataType *B, int64_t ldb, int64_t n, double alpha, double beta, DataType *C,
+                       int64_t ldc, void *ws, size_t ws_bytes)
+{
+    static const bool plans = [] {
+        const char *e = getenv("SBLAS_PLAN");
+        return !(e && e[0] == '0');
+    }();
+    if (plans && vt == SBLAS_F64 && it == SBLAS_I32 && pA->spmm_plan_gpu) {
+        if (pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] != n) {
+            (void)sblas_hip_spmm_plan_destroy(pA->spmm_plan_gpu[i]);
+            pA->spmm_plan_gpu[i] = NULL;
+            pA->spmm_plan_n[i] = 0;
+        }
+        if (!pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] != -n) { // first call at this width: remember it, run unplanned
+            pA->spmm_plan_n[i] = -n;
+            return sblas_hip_spmm_csr(-1, stream, vt, it, m, K, nnz, pA->csrRowPtr_gpu[i], pA->csrColIdx_gpu[i], pA->csrVal_gpu[i],
+                                      B, ldb, n, alpha, beta, C, ldc, ws, ws_bytes);
+        }
+        if (!pA->spmm_plan_gpu[i]) {
+            const int rc = sblas_hip_spmm_plan_create(-1, stream, m, K, nnz, (const int32_t *)pA->csrRowPtr_gpu[i],
+                                                      (const int32_t *)pA->csrColIdx_gpu[i], n, &pA->spmm_plan_gpu[i]);
+            if (rc != SBLAS_OK) return rc;
+            pA->spmm_plan_n[i] = n;
+        }
+        return sblas_hip_spmm_csr_f64_i32_planned(pA->spmm_plan_gpu[i], -1, stream, m, K, nnz, (const int32_t *)pA->csrRowPtr_gpu[i],
+                                                  (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
+                                                  (const double *)B, ldb, n, alpha, beta, (double *)C, ldc, ws, ws_bytes);
+    }
+    return sblas_hip_spmm_csr(-1, stream, vt, it, m, K, nnz, pA->csrRowPtr_gpu[i], pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], B, ldb,
+                              n, alpha, beta, C, ldc, ws, ws_bytes);
+}
+
 } // namespace sblas_detail
 
 // Method 1.  Preconditions (as the reference): A.sync2gpu(g, replicate); B, C .sync2gpu(g, segment), col-major.
@@ -92,9 +131,8 @@ void sblas_spmm_csr_v1(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         const size_t ws_bytes = sblas_hip_spmm_csr_workspace(vt, it, M, K, nnz, n_i);
         void *ws = sblas_rt::workspace(i, ws_bytes);
-        sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, sblas_rt::stream(i), vt, it, M, K, nnz, pA->csrRowPtr_gpu[i],
-                                                pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, n_i,
-                                                (double)alpha, (double)beta, pC->val_gpu[i], M, ws, ws_bytes),
+        sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, sblas_rt::stream(i), vt, it, M, K, nnz, pB->val_gpu[i], K, n_i,
+                                                       (double)alpha, (double)beta, pC->val_gpu[i], M, ws, ws_bytes),
                              "sblas_hip_spmm_csr");
     }
     for (unsigned i = 0; i < n_gpu; ++i) pC->sync2cpu(i); // stream-ordered after GPU i's kernels
@@ -150,17 +188,15 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
             // A_i * B accumulated (alpha = beta = 1) at its row offset, ld = M
             ccopy[i] = (DataType *)sblas_rt::workspace(i, cnt * sizeof(DataType), sblas_rt::WS_PARTIAL);
             CUDA_SAFE_CALL(hipMemsetAsync(ccopy[i], 0, cnt * sizeof(DataType), (hipStream_t)streams[i]));
-            sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, streams[i], vt, it, m_i, K, nnz_i, pA->csrRowPtr_gpu[i],
-                                                    pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, N, 1.0, 1.0,
-                                                    ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
+            sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, streams[i], vt, it, m_i, K, nnz_i, pB->val_gpu[i], K, N, 1.0, 1.0,
+                                                           ccopy[i] + (size_t)pA->starting_row_gpu[i], M, ws, ws_bytes),
                                  "sblas_hip_spmm_csr");
         } else {
             // packed m_i x N block, beta = 0: nothing to clear
             ccopy[i] = (DataType *)sblas_rt::workspace(i, (size_t)m_i * (size_t)N * sizeof(DataType), sblas_rt::WS_PARTIAL);
             gather[i] = (DataType *)sblas_rt::workspace(i, all_blocks * sizeof(DataType), sblas_rt::WS_GATHER);
-            sblas_rt::must_sblas(sblas_hip_spmm_csr(-1, streams[i], vt, it, m_i, K, nnz_i, pA->csrRowPtr_gpu[i],
-                                                    pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], pB->val_gpu[i], K, N, 1.0, 0.0,
-                                                    ccopy[i], m_i, ws, ws_bytes),
+            sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, streams[i], vt, it, m_i, K, nnz_i, pB->val_gpu[i], K, N, 1.0, 0.0,
+                                                           ccopy[i], m_i, ws, ws_bytes),
                                  "sblas_hip_spmm_csr");
         }
         timers[i] = new GPU_Timer((hipStream_t)streams[i]);

@@ -27,6 +27,7 @@ EXPORTS = [
     "sblas_mm_read_info", "sblas_mm_read_csr", "sblas_host_fill_rand0to1",
     "sblas_hip_spmm_csr_workspace", "sblas_hip_spmm_csr", "sblas_hip_spmv_csr", "sblas_hip_axpby",
     "sblas_hip_allreduce_sum", "sblas_hip_merge_rowblocks", "sblas_partition_nnz_i64",
+    "sblas_hip_spmm_plan_create", "sblas_hip_spmm_plan_destroy", "sblas_hip_spmm_plan_info", "sblas_hip_spmm_csr_f64_i32_planned",
 ]
 
 
@@ -60,6 +61,14 @@ def lib():
     L.sblas_hip_spmm_csr_f64_i32_workspace.argtypes = [i64, i64, i64, i64]
     L.sblas_hip_spmm_csr_f64_i32.restype = C.c_int
     L.sblas_hip_spmm_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64, vp, sz]
+    L.sblas_hip_spmm_plan_create.restype = C.c_int
+    L.sblas_hip_spmm_plan_create.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, i64, C.POINTER(vp)]
+    L.sblas_hip_spmm_plan_destroy.restype = C.c_int
+    L.sblas_hip_spmm_plan_destroy.argtypes = [vp]
+    L.sblas_hip_spmm_plan_info.restype = C.c_int
+    L.sblas_hip_spmm_plan_info.argtypes = [vp, C.POINTER(i64)]
+    L.sblas_hip_spmm_csr_f64_i32_planned.restype = C.c_int
+    L.sblas_hip_spmm_csr_f64_i32_planned.argtypes = [vp, C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64, vp, sz]
     L.sblas_hip_dense_to_rowmajor_f64.restype = C.c_int
     L.sblas_hip_dense_to_rowmajor_f64.argtypes = [C.c_int, vp, i64, i64, vp, i64, vp, i64]
     L.sblas_hip_spmm_csr_rowmajorB_f64_i32.restype = C.c_int
@@ -206,6 +215,51 @@ def spmm(rows, cols, rowptr, colidx, val, B, ldb, n, alpha, beta, Cmat, ldc, wor
         _dev_ptr(workspace, torch.float64, "workspace") if workspace is not None and workspace.numel() else None,
         workspace.numel() * 8 if workspace is not None else 0)
     check(rc, "sblas_hip_spmm_csr_f64_i32")
+
+
+class SpmmPlan:
+    """A per-matrix plan (sblas_hip_spmm_plan_create): the panel verdicts of one structure (rowptr, colidx) at one
+    width n, taken once.  Keeps the structure tensors alive; destroy() / garbage collection frees the device buffer."""
+
+    def __init__(self, rows, cols, rowptr, colidx, n, stream=None):
+        import torch
+        self.rows, self.cols, self.n, self.rowptr, self.colidx = rows, cols, n, rowptr, colidx
+        self.nnz = int(colidx.numel())
+        h = C.c_void_p()
+        check(lib().sblas_hip_spmm_plan_create(-1, _stream(stream), rows, cols, self.nnz, _dev_ptr(rowptr, torch.int32, "rowptr"),
+                                               _dev_ptr(colidx, torch.int32, "colidx") if self.nnz else None, n, C.byref(h)),
+              "sblas_hip_spmm_plan_create")
+        self.handle = h
+
+    def info(self):
+        out = (C.c_int64 * 8)()
+        check(lib().sblas_hip_spmm_plan_info(self.handle, out), "sblas_hip_spmm_plan_info")
+        return dict(active=bool(out[0]), windowed=int(out[1]), direct=int(out[2]), mfma=int(out[3]), merge=bool(out[4]),
+                    stage_range=bool(out[5]), ldbt=int(out[6]), panel_rows=int(out[7]))
+
+    def spmm(self, val, B, ldb, n, alpha, beta, Cmat, ldc, workspace, stream=None, c_offset=0):
+        """The planned form of spmm(): same arguments, same results, only the kernels that have panels are launched."""
+        import torch
+        rc = lib().sblas_hip_spmm_csr_f64_i32_planned(
+            self.handle, -1, _stream(stream), self.rows, self.cols, self.nnz,
+            _dev_ptr(self.rowptr, torch.int32, "rowptr"), _dev_ptr(self.colidx, torch.int32, "colidx") if self.nnz else None,
+            _dev_ptr(val, torch.float64, "val") if self.nnz else None,
+            _dev_ptr(B, torch.float64, "B") if self.cols else None, ldb, n, alpha, beta,
+            _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc,
+            _dev_ptr(workspace, torch.float64, "workspace") if workspace is not None and workspace.numel() else None,
+            workspace.numel() * 8 if workspace is not None else 0)
+        check(rc, "sblas_hip_spmm_csr_f64_i32_planned")
+
+    def destroy(self):
+        if self.handle:
+            lib().sblas_hip_spmm_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
 
 
 def dense_to_rowmajor(cols, n, B, ldb, Bt, stream=None):

@@ -79,6 +79,17 @@ def test_drivers_placement_and_merge_switches(sblas, cuda, env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{}, {"SBLAS_PLAN": "0"}])
+def test_repeated_calls_run_planned_through_the_header_layer(sblas, cuda, env):
+    """An iterative caller: sblas_spmm_csr_v1 / _v2 three times on one matrix.  The first call runs unplanned, the second
+    makes a per-GPU plan (kept in the CsrSparseMatrix until its next sync2gpu), the third runs on it; every call is
+    checked against the host verifier.  SBLAS_PLAN=0: no plans at all."""
+    for width, gpus in ((64, 1), (200, 2), (16, 4)):
+        rc, out = run("plan_test", ASH85, width, gpus, 3, env=env)
+        assert rc == 0 and "plan_test: PASS" in out and "MISMATCH" not in out, out[-1500:]
+
+
+@pytest.mark.gpu
 def test_unit_test_driver(sblas, cuda, tmp_path):
     shutil.copyfile(ASH85, tmp_path / "ash85.mtx")       # the driver's hard-coded ./ash85.mtx
     rc, out = run("unit_test", cwd=str(tmp_path))
