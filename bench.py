@@ -382,8 +382,12 @@ def product_method2(torch, S, O, devs, name, rows, cols, rp, ci, v, n, merge, st
     starts = [p["start_row"] for p in parts]
     nrows = [len(p["rowptr"]) - 1 for p in parts]
     total_blocks = sum(nrows) * n
-    A, Bs, Cs, streams, part, gath, ws = [], [], [], [], [], [], []
+    A, Bs, Cs, streams, mstreams, part, gath, ws = [], [], [], [], [], [], [], []
     shared_B = {}
+    piped = merge == "rowblocks_pipelined"
+    T = 128
+    ntiles = max(n // T, 1)
+    tiles = [(c * T, (n - c * T) if c == ntiles - 1 else T) for c in range(ntiles)]   # the last tile takes the remainder
     for q in range(g):
         td = tdev[q]
         with torch.cuda.device(td):
@@ -395,17 +399,57 @@ def product_method2(torch, S, O, devs, name, rows, cols, rp, ci, v, n, merge, st
             Bs.append(shared_B[devs[q]])
             Cs.append(torch.ones(M * n, dtype=torch.float64, device=td))
             streams.append(torch.cuda.Stream(device=td))
+            mstreams.append(torch.cuda.Stream(device=td))
             ws.append(torch.empty(max(S.spmm_workspace_bytes(nrows[q], K, k, n) // 8, 2), dtype=torch.float64, device=td))
             if merge == "allreduce":
                 part.append(torch.zeros(M * n, dtype=torch.float64, device=td))
-            else:
+            else:   # rowblocks, rowblocks_pipelined
                 part.append(torch.empty(max(nrows[q] * n, 1), dtype=torch.float64, device=td))
                 gath.append(None if folded or g == 1 else torch.empty(max(total_blocks, 1), dtype=torch.float64, device=td))
     for d_ in set(devs):
         torch.cuda.synchronize(d_)
     ev = [[[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(g)] for _ in range(steps)]
 
+    tl = [[torch.cuda.Event(enable_timing=True) for _ in range(1 + 2 * ntiles)] for _ in range(steps)]   # rank 0's timeline
+
+    def step_piped(k=None):
+        """spmm.h's column-tile pipeline: SpMM of tile c + 1 on the compute stream beside the exchange + scatter of tile c
+        on the rank's second stream."""
+        for q in range(g):
+            if k is not None:
+                ev[k][q][0].record(streams[q])
+        if k is not None:
+            tl[k][0].record(streams[0])
+        for c, (c0, tc) in enumerate(tiles):
+            for q in range(g):
+                with torch.cuda.device(tdev[q]):
+                    if nrows[q] > 0:
+                        S.spmm(nrows[q], K, A[q][0], A[q][1], A[q][2], Bs[q][c0 * K:(c0 + tc) * K], K, tc, 1.0, 0.0,
+                               part[q][c0 * nrows[q]:(c0 + tc) * nrows[q]], nrows[q], ws[q], stream=streams[q])
+                    done = torch.cuda.Event()
+                    done.record(streams[q])
+                    mstreams[q].wait_event(done)
+                    if k is not None and q == 0:
+                        tl[k][1 + 2 * c].record(streams[0])
+                    if k is not None and c == ntiles - 1:
+                        ev[k][q][1].record(streams[q])
+            gt = None if folded or g == 1 else [gath[q][c0 * sum(nrows):(c0 + tc) * sum(nrows)] for q in range(g)]
+            S.merge_rowblocks(comm, M, tc, starts, nrows, [part[q][c0 * nrows[q]:(c0 + tc) * nrows[q]] for q in range(g)], gt,
+                              1.0, 1.0, [Cs[q][c0 * M:(c0 + tc) * M] for q in range(g)], M, mstreams)
+            if k is not None:
+                tl[k][2 + 2 * c].record(mstreams[0])
+        for q in range(g):
+            with torch.cuda.device(tdev[q]):
+                fin = torch.cuda.Event()
+                fin.record(mstreams[q])
+                streams[q].wait_event(fin)
+                if k is not None:
+                    ev[k][q][2].record(streams[q])
+                    ev[k][q][3].record(streams[q])
+
     def step(k=None):
+        if piped:
+            return step_piped(k)
         for q in range(g):
             with torch.cuda.device(tdev[q]):
                 st = streams[q]
@@ -467,6 +511,13 @@ def product_method2(torch, S, O, devs, name, rows, cols, rp, ci, v, n, merge, st
            "oracle_check": ok, "oracle_max_abs_diff": err,
            "api": ("sblas_hip_comm_get + sblas_hip_allreduce_sum_f64 + sblas_hip_axpby_f64" if merge == "allreduce" else
                    "sblas_hip_comm_get + sblas_hip_merge_rowblocks_f64 (the scatter / alpha / beta pass is part of the merge)")}
+    if piped:
+        rel = lambda j: round(float(np.mean([e[0].elapsed_time(e[j]) for e in tl])), 5)
+        out["timeline_rank0_ms"] = [{"tile": c, "cols": tiles[c][1], "spmm_done": rel(1 + 2 * c), "merge_done": rel(2 + 2 * c)}
+                                    for c in range(ntiles)]
+        out["note"] = ("column-tile pipeline of sblas_spmm_csr_v2 (two streams per rank, events between them); ms_merge is the "
+                       "tail behind the last SpMM.  " + ("Ranks folded onto one GPU: the streams share it, what the overlap is "
+                       "worth over xGMI is unmeasured." if folded else ""))
     return out
 
 
@@ -480,7 +531,7 @@ def product_merge_sections(args, torch, S, devs4, devs8, rows, cols, rp, ci, v):
                                                   args.merge_steps, 2)
     qrows = args.queen_rows
     qrp, qci, qv = synth.queen_like(qrows)
-    for merge in ("rowblocks", "allreduce"):
+    for merge in ("rowblocks", "rowblocks_pipelined", "allreduce"):
         res["config5_" + merge] = product_method2(torch, S, O, devs8, "Queen_4147-like (scattered), %d rows" % qrows, qrows, qrows,
                                                   qrp, qci, qv, 256, merge, max(2, args.merge_steps // 2), 1)
         torch.cuda.empty_cache()

@@ -84,21 +84,18 @@ inline int spmm_on_gpu(CsrSparseMatrix<IdxType, DataType> *pA, unsigned i, void 
         return !(e && e[0] == '0');
     }();
     if (plans && vt == SBLAS_F64 && it == SBLAS_I32 && pA->spmm_plan_gpu) {
-        if (pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] != n) {
-            (void)sblas_hip_spmm_plan_destroy(pA->spmm_plan_gpu[i]);
-            pA->spmm_plan_gpu[i] = NULL;
-            pA->spmm_plan_n[i] = 0;
-        }
-        if (!pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] != -n) { // first call at this width: remember it, run unplanned
-            pA->spmm_plan_n[i] = -n;
-            return sblas_hip_spmm_csr(-1, stream, vt, it, m, K, nnz, pA->csrRowPtr_gpu[i], pA->csrColIdx_gpu[i], pA->csrVal_gpu[i],
-                                      B, ldb, n, alpha, beta, C, ldc, ws, ws_bytes);
-        }
-        if (!pA->spmm_plan_gpu[i]) {
+        // a plan speaks for a staged width: every n with the same sblas_hip_spmm_ldbt(n) shares it (method 2's column tiles)
+        const int64_t key = sblas_hip_spmm_ldbt(n);
+        const bool mine = pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] == key;
+        if (!mine && !pA->spmm_plan_gpu[i] && pA->spmm_plan_n[i] == -key) { // second call at this width: plan it
             const int rc = sblas_hip_spmm_plan_create(-1, stream, m, K, nnz, (const int32_t *)pA->csrRowPtr_gpu[i],
                                                       (const int32_t *)pA->csrColIdx_gpu[i], n, &pA->spmm_plan_gpu[i]);
             if (rc != SBLAS_OK) return rc;
-            pA->spmm_plan_n[i] = n;
+            pA->spmm_plan_n[i] = key;
+        } else if (!mine) { // first call at this width, or a width other than the plan's (a ragged last tile): unplanned
+            if (!pA->spmm_plan_gpu[i]) pA->spmm_plan_n[i] = -key;
+            return sblas_hip_spmm_csr(-1, stream, vt, it, m, K, nnz, pA->csrRowPtr_gpu[i], pA->csrColIdx_gpu[i], pA->csrVal_gpu[i],
+                                      B, ldb, n, alpha, beta, C, ldc, ws, ws_bytes);
         }
         return sblas_hip_spmm_csr_f64_i32_planned(pA->spmm_plan_gpu[i], -1, stream, m, K, nnz, (const int32_t *)pA->csrRowPtr_gpu[i],
                                                   (const int32_t *)pA->csrColIdx_gpu[i], (const double *)pA->csrVal_gpu[i],
@@ -107,6 +104,8 @@ inline int spmm_on_gpu(CsrSparseMatrix<IdxType, DataType> *pA, unsigned i, void 
     return sblas_hip_spmm_csr(-1, stream, vt, it, m, K, nnz, pA->csrRowPtr_gpu[i], pA->csrColIdx_gpu[i], pA->csrVal_gpu[i], B, ldb,
                               n, alpha, beta, C, ldc, ws, ws_bytes);
 }
+
+constexpr int64_t M2_TILE = 128; // column tile of method 2's SpMM / merge pipeline
 
 } // namespace sblas_detail
 
@@ -167,8 +166,11 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     const char *merge_mode = getenv("SBLAS_MERGE");
     const bool use_allreduce = merge_mode && !strcmp(merge_mode, "allreduce");
     std::vector<DataType *> ccopy(n_gpu, (DataType *)NULL), gather(n_gpu, (DataType *)NULL);
-    std::vector<void *> streams(n_gpu);
+    std::vector<void *> streams(n_gpu), mstreams(n_gpu);
     std::vector<GPU_Timer *> timers(n_gpu);
+    // two or more 128-column tiles: pipeline SpMM and merge over the tiles (SBLAS_M2_PIPELINE=0: one piece, serial)
+    const char *pipe_mode = getenv("SBLAS_M2_PIPELINE");
+    const bool pipelined = !use_allreduce && N >= 2 * sblas_detail::M2_TILE && !(pipe_mode && pipe_mode[0] == '0');
     std::vector<int64_t> starts(n_gpu), nrows(n_gpu);
     size_t all_blocks = 0;
     for (unsigned i = 0; i < n_gpu; ++i) {
@@ -179,6 +181,7 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
     for (unsigned i = 0; i < n_gpu; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         streams[i] = sblas_rt::stream(i);
+        mstreams[i] = sblas_rt::merge_stream(i);
         const int64_t m_i = nrows[i];
         const int64_t nnz_i = (int64_t)pA->nnz_gpu[i];
         const size_t ws_bytes = sblas_hip_spmm_csr_workspace(vt, it, m_i, K, nnz_i, N);
@@ -195,26 +198,69 @@ void sblas_spmm_csr_v2(CsrSparseMatrix<IdxType, DataType> *pA, DenseMatrix<IdxTy
             // packed m_i x N block, beta = 0: nothing to clear
             ccopy[i] = (DataType *)sblas_rt::workspace(i, (size_t)m_i * (size_t)N * sizeof(DataType), sblas_rt::WS_PARTIAL);
             gather[i] = (DataType *)sblas_rt::workspace(i, all_blocks * sizeof(DataType), sblas_rt::WS_GATHER);
-            sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, streams[i], vt, it, m_i, K, nnz_i, pB->val_gpu[i], K, N, 1.0, 0.0,
-                                                           ccopy[i], m_i, ws, ws_bytes),
-                                 "sblas_hip_spmm_csr");
+            if (!pipelined)
+                sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, streams[i], vt, it, m_i, K, nnz_i, pB->val_gpu[i], K, N, 1.0, 0.0,
+                                                               ccopy[i], m_i, ws, ws_bytes),
+                                     "sblas_hip_spmm_csr");
         }
-        timers[i] = new GPU_Timer((hipStream_t)streams[i]);
-        timers[i]->start_timer();
+        timers[i] = new GPU_Timer((hipStream_t)(pipelined ? mstreams[i] : streams[i]));
+        if (!pipelined) timers[i]->start_timer();
     }
     if (use_allreduce) {
         // sum of the partial C over all GPUs (RCCL over xGMI; stream-ordered after each GPU's SpMM)
         sblas_rt::must_sblas(sblas_hip_allreduce_sum(comm, vt, (void *const *)ccopy.data(), streams.data(), (int64_t)cnt),
                              "sblas_hip_allreduce_sum");
-    } else {
+    } else if (!pipelined) {
         std::vector<void *> cptr(n_gpu);
         for (unsigned i = 0; i < n_gpu; ++i) cptr[i] = pC->val_gpu[i];
         sblas_rt::must_sblas(sblas_hip_merge_rowblocks(comm, vt, M, N, starts.data(), nrows.data(),
                                                        (void *const *)ccopy.data(), (void *const *)gather.data(),
                                                        (double)alpha, (double)beta, cptr.data(), M, streams.data()),
                              "sblas_hip_merge_rowblocks");
+    } else {
+        // Column-tile pipeline (the reference is fully serial, spmm.h:253-265): the SpMM of tile c + 1 runs on the compute
+        // stream while tile c's blocks are exchanged and scattered on the GPU's second stream.  A tile of the packed
+        // m_i x N block is contiguous (columns [c T, c T + T) at leading dimension m_i), its gather region and its
+        // columns of C likewise; the terms of every element are added in the same order as in the one-piece merge.
+        // (the last tile takes the remainder, 128..255 columns: every tile then runs the 128-column kernels the one-piece
+        //  call runs, and the result is the same bit for bit)
+        const int64_t T = sblas_detail::M2_TILE;
+        const int64_t ntiles = N / T;
+        size_t rows_all = 0;
+        for (unsigned i = 0; i < n_gpu; ++i) rows_all += (size_t)nrows[i];
+        for (int64_t c = 0; c < ntiles; ++c) {
+            const int64_t c0 = c * T, Tc = (c == ntiles - 1) ? N - c0 : T;
+            std::vector<void *> ptile(n_gpu), gtile(n_gpu), ctile(n_gpu);
+            for (unsigned i = 0; i < n_gpu; ++i) {
+                CUDA_SAFE_CALL(cudaSetDevice((int)i));
+                const int64_t m_i = nrows[i], nnz_i = (int64_t)pA->nnz_gpu[i];
+                const size_t ws_bytes = sblas_hip_spmm_csr_workspace(vt, it, m_i, K, nnz_i, N);
+                void *ws = sblas_rt::workspace(i, ws_bytes);
+                ptile[i] = ccopy[i] + (size_t)c0 * (size_t)m_i;
+                gtile[i] = gather[i] + (size_t)c0 * rows_all;
+                ctile[i] = pC->val_gpu[i] + (size_t)c0 * (size_t)M;
+                sblas_rt::must_sblas(sblas_detail::spmm_on_gpu(pA, i, streams[i], vt, it, m_i, K, nnz_i,
+                                                               pB->val_gpu[i] + (size_t)c0 * (size_t)K, K, Tc, 1.0, 0.0,
+                                                               (DataType *)ptile[i], m_i, ws, ws_bytes),
+                                     "sblas_hip_spmm_csr");
+                hipEvent_t done = sblas_rt::event(i, (size_t)c);
+                CUDA_SAFE_CALL(hipEventRecord(done, (hipStream_t)streams[i]));
+                CUDA_SAFE_CALL(hipStreamWaitEvent((hipStream_t)mstreams[i], done, 0));
+                if (c == 0) timers[i]->start_timer();
+            }
+            sblas_rt::must_sblas(sblas_hip_merge_rowblocks(comm, vt, M, Tc, starts.data(), nrows.data(), ptile.data(), gtile.data(),
+                                                           (double)alpha, (double)beta, ctile.data(), M, mstreams.data()),
+                                 "sblas_hip_merge_rowblocks");
+        }
+        for (unsigned i = 0; i < n_gpu; ++i) { // the op's result is ordered on the GPU's first stream, as without the pipeline
+            CUDA_SAFE_CALL(cudaSetDevice((int)i));
+            timers[i]->stop_timer();
+            hipEvent_t merged = sblas_rt::event(i, (size_t)ntiles);
+            CUDA_SAFE_CALL(hipEventRecord(merged, (hipStream_t)mstreams[i]));
+            CUDA_SAFE_CALL(hipStreamWaitEvent((hipStream_t)streams[i], merged, 0));
+        }
     }
-    for (unsigned i = 0; i < n_gpu; ++i) {
+    for (unsigned i = 0; i < n_gpu && !pipelined; ++i) {
         CUDA_SAFE_CALL(cudaSetDevice((int)i));
         timers[i]->stop_timer();
         if (use_allreduce) {

@@ -60,6 +60,8 @@ inline int physical_device(unsigned logical)
 enum { WS_STAGING = 0, WS_PARTIAL = 1, WS_GATHER = 2, WS_SLOTS = 3 };
 struct PerGpu {
     hipStream_t stream = nullptr;
+    hipStream_t merge_stream = nullptr;   // method 2: the exchange + scatter of column tile c runs here, beside the SpMM of tile c + 1
+    std::vector<hipEvent_t> events;       // (grow-only pool)
     void *workspace[WS_SLOTS] = {nullptr, nullptr, nullptr};
     size_t workspace_bytes[WS_SLOTS] = {0, 0, 0};
 };
@@ -99,6 +101,30 @@ inline hipStream_t stream(unsigned logical)
         must(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking), "hipStreamCreate");
     }
     return g.stream;
+}
+
+// the second stream of a logical GPU (method 2's merge) and events to order it against the first
+inline hipStream_t merge_stream(unsigned logical)
+{
+    std::lock_guard<std::mutex> lock(table_mutex());
+    PerGpu &g = table()[logical];
+    if (!g.merge_stream) {
+        must(hipSetDevice(physical_device(logical)), "hipSetDevice");
+        must(hipStreamCreateWithFlags(&g.merge_stream, hipStreamNonBlocking), "hipStreamCreate");
+    }
+    return g.merge_stream;
+}
+inline hipEvent_t event(unsigned logical, size_t k)
+{
+    std::lock_guard<std::mutex> lock(table_mutex());
+    PerGpu &g = table()[logical];
+    while (g.events.size() <= k) {
+        hipEvent_t e = nullptr;
+        must(hipSetDevice(physical_device(logical)), "hipSetDevice");
+        must(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        g.events.push_back(e);
+    }
+    return g.events[k];
 }
 
 // grow-only scratch buffers per logical GPU: the "externalBuffer" of the replaced cuSPARSE calls (spmm.h:134-141)

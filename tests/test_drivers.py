@@ -84,9 +84,18 @@ def test_repeated_calls_run_planned_through_the_header_layer(sblas, cuda, env):
     """An iterative caller: sblas_spmm_csr_v1 / _v2 three times on one matrix.  The first call runs unplanned, the second
     makes a per-GPU plan (kept in the CsrSparseMatrix until its next sync2gpu), the third runs on it; every call is
     checked against the host verifier.  SBLAS_PLAN=0: no plans at all."""
-    for width, gpus in ((64, 1), (200, 2), (16, 4)):
+    for width, gpus in ((64, 1), (200, 2), (16, 4), (256, 2)):
         rc, out = run("plan_test", ASH85, width, gpus, 3, env=env)
         assert rc == 0 and "plan_test: PASS" in out and "MISMATCH" not in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,gpus", [(256, 4), (300, 2), (130, 3), (520, 2)])
+def test_method2_column_tile_pipeline_is_bit_identical_to_the_serial_form(sblas, cuda, width, gpus):
+    """sblas_spmm_csr_v2 pipelines SpMM and merge over 128-column tiles on two streams per GPU (the reference is serial,
+    spmm.h:253-265): same bits as the one-piece form, a ragged last tile included, and both match the host verifier."""
+    rc, out = run("pipeline_test", ASH85, width, gpus)
+    assert rc == 0 and "pipeline_test: PASS" in out and "bit-identical: yes" in out, out[-1500:]
 
 
 @pytest.mark.gpu
