@@ -245,6 +245,7 @@ constexpr int PANEL_ROWS = 32;   // narrow kernels (256 threads)
 constexpr int WIDE_WAVES = 16;
 constexpr int WIDE_ROWS_PER_WAVE = 1;
 constexpr int WIDE_PANEL = WIDE_WAVES * WIDE_ROWS_PER_WAVE;
+constexpr int DPP_LONG = 4096;            // entries from which a row of the row-per-wave kernel is computed by the whole workgroup
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one).  Give every XCD one contiguous
 // range of panels so that neighbouring panels -- which read overlapping Bt rows -- share an L2 (speed only;
@@ -1426,7 +1427,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
-    int info_panel_rows, int interleave, int epoch)
+    int info_panel_rows, int interleave, int epoch, int long_min)
 {
     static_assert(GROUPS == 1 || GROUPS == 2 || GROUPS == 4, "lane groups of 64, 32 or 16 lanes");
     constexpr int TILE_COLS = 128 / GROUPS;
@@ -1468,9 +1469,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     const char *__restrict__ bt_bytes = reinterpret_cast<const char *>(Bt);
 
     double acc0 = 0.0, acc1 = 0.0;
-    if (mine) {
-        const int p0 = wave_uniform(rowptr[row]);
-        const int p1 = wave_uniform(rowptr[row + 1]);
+    // entries [p0, p1) of one row into (acc0, acc1)
+    auto sweep = [&](int p0, int p1) {
         for (int p = p0; p < p1; p += WAVE) {
             const int mine = p + lane;
             int cj = 0;
@@ -1521,7 +1521,23 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
 #undef SBLAS_LD
             }
         }
+    };
+    // Skewed matrices: a row of tens of thousands of entries would keep ONE wave busy while the other fifteen of the
+    // workgroup -- and, at the tail of the launch, the whole chip -- wait for it.  Rows of DPP_LONG+ entries are set
+    // aside and computed by all sixteen waves together afterwards (each wave a slice of whole 64-entry chunks, the
+    // sixteen partial sums added in LDS in wave order), the rule of spmm_direct_rows_kernel.
+    __shared__ int long_wave[WIDE_PANEL];
+    __shared__ int n_long;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
+    int rp0 = 0, rp1 = 0;
+    if (mine) {
+        rp0 = wave_uniform(rowptr[row]);
+        rp1 = wave_uniform(rowptr[row + 1]);
     }
+    const bool is_long = mine && rp1 - rp0 >= long_min;
+    if (is_long && lane == 0) long_wave[atomicAdd(&n_long, 1)] = wave;
+    if (mine && !is_long) sweep(rp0, rp1);
     if (GROUPS == 4) { // the lane groups summed different nonzeros of the same row
         acc0 += __shfl_xor(acc0, 16, WAVE);
         acc1 += __shfl_xor(acc1, 16, WAVE);
@@ -1538,6 +1554,37 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
         ctile[cl + 1][wave] = acc1;
     }
     __syncthreads();
+    if (n_long > 0) { // (workgroup-uniform; no trips for all but a few panels of a skewed matrix)
+        __shared__ double lpart[WIDE_WAVES][TILE_COLS];
+        for (int i = 0; i < n_long; ++i) {
+            const int lw = long_wave[i];
+            const int pa = rowptr[row0 + lw], pb = rowptr[row0 + lw + 1];
+            const int slice = ((pb - pa + WIDE_WAVES - 1) / WIDE_WAVES + 63) & ~63; // whole 64-entry chunks per wave
+            const int s0 = min(pa + wave * slice, pb), s1 = min(s0 + slice, pb);
+            acc0 = acc1 = 0.0;
+            sweep(s0, s1);
+            if (GROUPS == 4) {
+                acc0 += __shfl_xor(acc0, 16, WAVE);
+                acc1 += __shfl_xor(acc1, 16, WAVE);
+            }
+            if (GROUPS >= 2) {
+                acc0 += __shfl_xor(acc0, 32, WAVE);
+                acc1 += __shfl_xor(acc1, 32, WAVE);
+            }
+            if (lane < GLANES) {
+                lpart[wave][2 * lane] = acc0;
+                lpart[wave][2 * lane + 1] = acc1;
+            }
+            __syncthreads();
+            if (threadIdx.x < TILE_COLS) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WIDE_WAVES; ++w) t += lpart[w][threadIdx.x];
+                ctile[threadIdx.x][lw] = t;
+            }
+            __syncthreads();
+        }
+    }
     const int nrows = min(WIDE_PANEL, rows - row0);
     const int ncols = min(TILE_COLS, n - col0);
     for (int idx = threadIdx.x; idx < TILE_COLS * WIDE_PANEL; idx += WIDE_WAVES * 64) {
@@ -2155,8 +2202,13 @@ static void options_parse(Options &o)
         o.panel_groups = strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0;
     }
     if ((e = getenv("SBLAS_MFMA_MIN_FILL")) && *e) o.mfma_min_fill = (float)atof(e);
-    if ((e = getenv("SBLAS_TUNE")) && *e) { /* "a,b,c,d": free integers for kernel experiments */
-        sscanf(e, "%d,%d,%d,%d", &o.tune[0], &o.tune[1], &o.tune[2], &o.tune[3]);
+    if ((e = getenv("SBLAS_TUNE")) && *e) { /* "a,b,c,d" (or "a:b:c:d"): free integers for kernel experiments */
+        char buf[96];
+        strncpy(buf, e, sizeof buf - 1);
+        buf[sizeof buf - 1] = 0;
+        for (char *c = buf; *c; ++c)
+            if (*c == ':') *c = ',';
+        sscanf(buf, "%d,%d,%d,%d", &o.tune[0], &o.tune[1], &o.tune[2], &o.tune[3]);
     }
 }
 const Options &options()
@@ -2482,6 +2534,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
 {
     const Options &opt = options();
     const double avg_row = rows > 0 ? (double)nnz / (double)rows : 0.0;
+    const int dpp_long = opt.tune[2] > 0 ? opt.tune[2] : DPP_LONG; // (SBLAS_TUNE=*,*,<entries>: A/B runs of the long-row split)
     // a planned call (pv): the verdicts sit in the plan's buffer, nothing is classified or voted on, and only the kernels
     // that have panels are launched
     const bool need_window = !pv || pv->n_window + pv->n_mfma_w > 0;
@@ -2561,12 +2614,12 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<4>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
                                rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls,
-                               info_rows, interleave, epoch);
+                               info_rows, interleave, epoch, dpp_long);
         } else if (ldbt == 64) {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<2>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<2>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
                                rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls,
-                               info_rows, interleave, epoch);
+                               info_rows, interleave, epoch, dpp_long);
         } else {
             // 128-column tiles.  Classified calls launch both direct kernels: the classifier's vote (device side) says
             // whether the rows share column patterns, and the kernel whose call it is not leaves on one scalar load.
@@ -2585,7 +2638,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<1>, pad);
                 hipLaunchKernelGGL(spmm_direct_dpp_kernel<1>, dim3((unsigned)wide_panels, (unsigned)(ldbt / 128)),
                                    dim3(WIDE_WAVES * 64), pad, s, rows, cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n,
-                                   alpha, beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch);
+                                   alpha, beta, C, ldc, t.hdr, cls, info_rows, interleave, epoch, dpp_long);
             }
         }
     } else {
@@ -2645,7 +2698,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), 0, s, rows,
                                cols, wide_panels, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
-                               opt.direct_map, epoch);
+                               opt.direct_map, epoch, dpp_long);
         } else if (ldbt == 32) {
             hipLaunchKernelGGL(spmm_rowpanel_narrow_kernel<32>, dim3(panels), dim3(256), 0, s, rows, rowptr, colidx, val,
                                Bt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows, epoch);

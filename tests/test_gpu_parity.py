@@ -939,6 +939,37 @@ def test_spmm_power_law_rows(env, variant_env, variant, n):
     assert close(got, ref), (variant, n, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("variant", ["auto", "dpp"])
+@pytest.mark.parametrize("n", [16, 64, 128, 256])
+def test_spmm_row_per_wave_kernel_splits_very_long_rows(env, variant_env, variant, n):
+    """The row-per-wave direct kernel (every width: 32- / 64- / 128-column tiles) hands rows of 4096+ entries to the
+    whole workgroup: sixteen slices, partial sums added in LDS.  Rows average 40 entries (so that `auto` picks this
+    kernel, not the four-rows-per-wave one) with a tail: one row just under the limit, one just over, one of 20 000
+    entries with duplicates, two long rows in one 16-row panel, a long last row."""
+    sblas, oracle, torch, dev = env
+    variant_env(variant)
+    M, K = 1203, 30000
+    rng = np.random.default_rng(n)
+    lens = rng.integers(30, 50, M).astype(np.int64)
+    lens[[5, 17, 40, 320, 321, M - 1]] = (4095, 4096, 20000, 5000, 4500, 7001)
+    lens[100] = 0
+    rp = np.zeros(M + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.empty(rp[-1], np.int32)
+    for r in range(M):
+        ci[rp[r]:rp[r + 1]] = np.sort(rng.integers(0, K, lens[r]))      # (with replacement: duplicates in the long rows)
+    v = rng.standard_normal(rp[-1])
+    A = Dev(torch, dev, rp.astype(np.int32), ci, v, K)
+    B, C0 = rng.standard_normal(K * n), rng.standard_normal(M * n)
+    sblas.panel_census()
+    got = gpu_spmm(sblas, torch, dev, A, B, K, n, 1.5, -0.5, C0, M)
+    census = sblas.panel_census()
+    ref = oracle.spmm(M, K, n, *A.h, B, C0.copy(), 1.5, -0.5)
+    assert close(got, ref), (variant, n, np.abs(got - ref).max())
+    if variant == "auto":
+        assert census["direct"] > 0, census
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the matrix-core (MFMA) kernel: panels whose nonzeros sit in dense 16 x 4 sub-blocks
 # ---------------------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ one process, median of the rounds), with the panel census and an oracle check of
     blocksw[:rows[:fill]]      16 x 4 sub-blocks, 80 per row, over a +-50 000 band (direct-class panels)
     queen[:rows]               Queen-like, 40 scattered offsets (synth.queen_like)
     qgrid[:rows[:dofs[:hb]]]   Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node and a +-50 000 band unless given
-    powerlaw[:rows]            webbase-like row lengths (synth.powerlaw)
+    powerlaw[:rows[:avg[:max]]] webbase-like row lengths (synth.powerlaw)
     uniform:rows:avg           binomial row lengths, columns anywhere (synth.random_csr)
 Environment switches of the library can be set per variant as name=ENV1=val1+ENV2=val2."""
 import argparse, os, sys, time
@@ -45,7 +45,7 @@ def make(shape):
         rp, ci, v = synth.random_csr(rows, rows, float(parts[2]), sorted_rows=len(parts) > 3)
     elif kind == "powerlaw":
         rows = int(parts[1]) if len(parts) > 1 else 1000000
-        rp, ci, v = synth.powerlaw(rows)
+        rp, ci, v = synth.powerlaw(rows, avg=float(parts[2]) if len(parts) > 2 else 3.0, max_len=int(parts[3]) if len(parts) > 3 else 5000)
     else:
         raise SystemExit("unknown shape " + shape)
     return rows, rp, ci, v
