@@ -106,6 +106,11 @@ int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream,
  * windowed and then recomputed by the in-kernel fallback (rows not in ascending column order) [2], or the matrix-core
  * (MFMA) path [3]. */
 int sblas_hip_debug_spmm_panel_stats(uint64_t out[4], int reset);
+/* Opt-in check of the CONTENTS of a CSR structure on the device (synchronises `stream`): row pointers ascending from 0 to
+ * nnz, column indices inside [0, cols).  SBLAS_OK / SBLAS_E_INVALID.  The compute entry points trust the contents (as
+ * cuSPARSE does); SBLAS_VALIDATE=1 makes every SpMM / SpMV call run this check first (debugging). */
+int sblas_hip_debug_validate_csr_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz,
+                                     const int32_t *rowptr, const int32_t *colidx);
 /* The library reads its experiment switches (SBLAS_SPMM_VARIANT, SBLAS_SPMV_VARIANT, ...; none changes a result) from
  * the environment once, at the first launch.  A process that changes them afterwards (the test-suite does) calls this
  * to have them read again. */

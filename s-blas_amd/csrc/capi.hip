@@ -1,6 +1,8 @@
 // capi.hip -- the extern "C" surface declared in include/sblas_hip.h (compute entry points).
-// Argument checking happens here, on the host, before any kernel is launched: a bad shape must
-// come back as SBLAS_E_INVALID, never as a faulting wave.
+// Argument checking happens here, on the host, before any kernel is launched: a bad shape, leading dimension, pointer or
+// workspace comes back as SBLAS_E_INVALID / SBLAS_E_WORKSPACE.  The CONTENTS of the index arrays are the caller's
+// contract, as with the vendor libraries this replaces (a column index outside [0, cols) is an out-of-bounds read);
+// SBLAS_VALIDATE=1 / sblas_hip_debug_validate_csr_i32 check them on the device first, at the price of a synchronisation.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdlib.h>
@@ -189,6 +191,9 @@ int sblas_hip_spmm_csr_rowmajorB_f64_i32(int dev, void *stream, int64_t rows, in
     return spmm_staged(dev, stream, rows, cols, nnz, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, 0);
 }
 
+static int validate_if_asked(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                             const int32_t *colidx);
+
 // A plan: the panel verdicts of one matrix structure at one staged width, taken once (sblas_hip_spmm_plan_create).
 struct SpmmPlan {
     int dev = -1;
@@ -208,6 +213,7 @@ static int spmm_impl(int dev, void *stream, int64_t rows, int64_t cols, int64_t 
     if (!C || ldc < rows) return SBLAS_E_INVALID;
     if (cols > 0 && (!B || ldb < cols)) return SBLAS_E_INVALID;
     if (cols == 0 || nnz == 0) return scale_only(dev, stream, rows, n, beta, C, ldc);
+    if (const int vrc = validate_if_asked(dev, stream, rows, cols, nnz, rowptr, colidx)) return vrc;
     const size_t need = sblas_hip_spmm_csr_f64_i32_workspace(rows, cols, nnz, n);
     if (need > 0 && (!workspace || workspace_bytes < need)) return SBLAS_E_WORKSPACE;
     double *Bt = static_cast<double *>(workspace);
@@ -343,6 +349,24 @@ int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream, 
     return spmm_impl(dev, stream, rows, cols, nnz, rowptr, colidx, val, B, ldb, n, alpha, beta, C, ldc, workspace, workspace_bytes, p);
 }
 
+int sblas_hip_debug_validate_csr_i32(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                                     const int32_t *colidx)
+{
+    if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, reinterpret_cast<const void *>(1))) return SBLAS_E_INVALID;
+    if (rows == 0) return SBLAS_OK;
+    DeviceScope scope(dev);
+    if (scope.err != hipSuccess) return SBLAS_E_HIP;
+    int bad = 0;
+    if (sblas::validate_csr((hipStream_t)stream, rows, cols, nnz, rowptr, colidx, &bad) != hipSuccess) return SBLAS_E_HIP;
+    return bad ? SBLAS_E_INVALID : SBLAS_OK;
+}
+static int validate_if_asked(int dev, void *stream, int64_t rows, int64_t cols, int64_t nnz, const int32_t *rowptr,
+                             const int32_t *colidx)
+{
+    if (!sblas::options().validate || rows <= 0 || nnz <= 0) return SBLAS_OK;
+    return sblas_hip_debug_validate_csr_i32(dev, stream, rows, cols, nnz, rowptr, colidx);
+}
+
 int sblas_hip_debug_reload_env(void)
 {
     sblas::options_reload();
@@ -377,6 +401,7 @@ int sblas_hip_spmv_csr_f64_i32(int dev, void *stream, int64_t rows, int64_t cols
     if (!csr_args_ok(rows, cols, nnz, rowptr, colidx, val)) return SBLAS_E_INVALID;
     if (rows == 0) return SBLAS_OK;
     if (!y || (cols > 0 && !x)) return SBLAS_E_INVALID;
+    if (const int vrc = validate_if_asked(dev, stream, rows, cols, nnz, rowptr, colidx)) return vrc;
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) return SBLAS_E_HIP;
     return sblas::launch_spmv((hipStream_t)stream, (int)rows, (int)cols, nnz, rowptr, colidx, val, x, alpha, beta, y) ==

@@ -171,21 +171,26 @@ inline bool parse_real(const char *&p, const char *end, double &out)
     return true;
 }
 
-// one entry = tpe whitespace-separated tokens: "i j [re [im]]"
+// one entry = tpe whitespace-separated tokens: "i j [re [im]]".  STRICT (the threaded tokenizer): every field must end at
+// whitespace or at the end of the buffer -- fscanf semantics let a conversion stop INSIDE a token ("1+2 3.0" is one
+// entry for the sequential loop but two whitespace tokens for the chunk arithmetic), and such a file must go to the
+// sequential loop, which mirrors the reference, instead of being realigned at a chunk boundary.
+template <bool STRICT = false>
 inline bool parse_entry(const char *&p, const char *end, Field field, long M, long N, bool mirrored, int32_t &ri,
                         int32_t &ci, double &v)
 {
     long i = 0, j = 0;
     double re = 1.0;
-    if (!parse_int(p, end, i) || !parse_int(p, end, j)) return false;
+    auto whole = [&]() { return !STRICT || p >= end || isspace((unsigned char)*p); };
+    if (!parse_int(p, end, i) || !whole() || !parse_int(p, end, j) || !whole()) return false;
     if (field == F_REAL) {
-        if (!parse_real(p, end, re)) return false;
+        if (!parse_real(p, end, re) || !whole()) return false;
     } else if (field == F_COMPLEX) {
         double im;
-        if (!parse_real(p, end, re) || !parse_real(p, end, im)) return false; // imaginary part dropped
+        if (!parse_real(p, end, re) || !whole() || !parse_real(p, end, im) || !whole()) return false; // imaginary part dropped
     } else if (field == F_INTEGER) {
         long iv;
-        if (!parse_int(p, end, iv)) return false;
+        if (!parse_int(p, end, iv) || !whole()) return false;
         re = (double)(int)iv;
     }
     if (i < 1 || i > M || j < 1 || j > N) return false; // the reference would write out of bounds
@@ -254,7 +259,7 @@ bool parse_entries_parallel(const char *p, const char *end, long NZ, Field field
             q = token_end(q, end);
         }
         for (long long e = e0; e < e1; ++e) {
-            if (!parse_entry(q, end, field, M, N, mirrored, ri[(size_t)e], ci[(size_t)e], v[(size_t)e])) {
+            if (!parse_entry<true>(q, end, field, M, N, mirrored, ri[(size_t)e], ci[(size_t)e], v[(size_t)e])) {
                 bad.store(true);
                 return;
             }

@@ -59,6 +59,7 @@ struct Options {
     float window_density = 0.42f;         // SBLAS_WINDOW_DENSITY: the LDS-tiled kernel's bar, in nonzeros per spanned column of a 16-row slice of a panel
     int panel_rows = 0, panel_groups = 0; // SBLAS_SPMM_PANEL_ROWS
     int tune[4] = {0, 0, 0, 0};           // SBLAS_TUNE
+    bool validate = false;                // SBLAS_VALIDATE=1: every SpMM / SpMV call checks the CSR contents first (synchronises; debugging)
     float mfma_min_fill = -1.0f;          // SBLAS_MFMA_MIN_FILL: block fill from which a panel takes the MFMA kernel (< 0: built-in rule)
 };
 const Options &options();
@@ -95,11 +96,11 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
                                  int64_t ldbt, int rows, const int *rowptr, const int *colidx, int variant,
                                  int *epoch_out);
 hipError_t launch_scale(hipStream_t s, int64_t rows, int64_t n, double beta, double *C, int64_t ldc);
+hipError_t validate_csr(hipStream_t s, int64_t rows, int64_t cols, int64_t nnz, const int *rowptr, const int *colidx, int *bad);
 hipError_t panel_stats(unsigned long long out[4], bool reset);
 hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                        const double *val, const double *x, double alpha, double beta, double *y);
 hipError_t launch_axpby(hipStream_t s, int64_t n, double alpha, const double *x, double beta, double *y);
-hipError_t launch_sum_replicas(hipStream_t s, const ReplicaPtrs &bufs, int g, int64_t n);
 void kernel_events_enable(bool on);
 hipError_t kernel_events_last_ms(float *ms);
 hipError_t launch_merge_rowblocks(hipStream_t s, int64_t M, int64_t N, int g, const double *const *src,

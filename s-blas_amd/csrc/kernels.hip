@@ -18,7 +18,6 @@
 //   axpby_kernel                 y = beta*y + alpha*x                                        (kernel.h:27-38)
 //   scale_kernel                 C = beta*C (a matrix without nonzeros)
 //   merge_rowblocks_kernel       method-2 / SpMV merge: scatter packed row blocks, apply alpha / beta
-//   sum_replicas_kernel          in-place sum over g buffers that live on ONE device (folded ranks)
 // (SpMV kernels: spmv_kernels.hip.)
 //
 // These replace the closed-source cuSPARSE calls of the reference (spmm.h:146-149, :248-251) and its one utility
@@ -2070,18 +2069,6 @@ __global__ __launch_bounds__(256) void scale_kernel(int64_t rows, int64_t n, dou
     }
 }
 
-// In-place sum of g replicas that share a device: every buffer ends up holding the sum, added in
-// rank order (the single-device stand-in for the all-reduce when ranks are oversubscribed).
-__global__ __launch_bounds__(256) void sum_replicas_kernel(ReplicaPtrs bufs, int g, int64_t n)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        double s = 0.0;
-        for (int q = 0; q < g; ++q) s += bufs.p[q][i];
-        for (int q = 0; q < g; ++q) bufs.p[q][i] = s;
-    }
-}
-
 // Method-2 merge without an all-reduce.  The partial results of the row-block scheme are disjoint
 // except for the rows a block boundary cuts, so every GPU only needs the OTHER GPUs' blocks (packed, m_q x N,
 // leading dimension m_q) and one pass that scatters them into place and applies alpha / beta:
@@ -2123,22 +2110,60 @@ static inline unsigned capped_grid(int64_t work_items, int per_block)
 }
 
 
+// Opt-in check of the CONTENTS of a CSR structure (sblas_hip_debug_validate_csr_i32, SBLAS_VALIDATE=1): the compute
+// kernels trust them, as the vendor libraries do -- a column index outside [0, cols) is an out-of-bounds read of Bt.
+// flag[0] |= 1: a row pointer runs backwards or past nnz; 2: rowptr[0] != 0 or rowptr[rows] != nnz; 4: a column index
+// outside [0, cols).
+__global__ __launch_bounds__(256) void validate_csr_kernel(int64_t rows, int64_t cols, int64_t nnz, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ colidx, int *__restrict__ flag)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    for (int64_t r = tid; r < rows; r += stride) {
+        const int a = rowptr[r], b = rowptr[r + 1];
+        if (a > b || a < 0 || (int64_t)b > nnz) bad |= 1;
+    }
+    if (tid == 0 && (rowptr[0] != 0 || (int64_t)rowptr[rows] != nnz)) bad |= 2;
+    for (int64_t k = tid; k < nnz; k += stride) {
+        const int c = colidx[k];
+        if (c < 0 || (int64_t)c >= cols) bad |= 4;
+    }
+    if (bad) atomicOr(flag, bad);
+}
+hipError_t validate_csr(hipStream_t s, int64_t rows, int64_t cols, int64_t nnz, const int *rowptr, const int *colidx, int *bad)
+{
+    int *flag = nullptr;
+    hipError_t e = hipMalloc(&flag, sizeof(int));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(validate_csr_kernel, dim3(capped_grid(std::max<int64_t>(rows, nnz), 256)), dim3(256), 0, s, rows, cols, nnz,
+                           rowptr, colidx, flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(flag);
+    return e;
+}
+
 // compute units of the current device (queried once per device)
 static int compute_units()
 {
-    static int cached[16] = {0};
+    static std::atomic<int> cached[16]; // (zero-initialised; any thread may fill a slot, all write the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
-    if (cached[dev] <= 0) {
-        int n = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
-        cached[dev] = n;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return n;
 }
 
 // Diagnostics: two events around the dominant stage-2 kernel of the most recent launch on a device (see
-// sblas_hip_debug_spmm_kernel_events).
+// sblas_hip_debug_spmm_kernel_events).  NOT thread-safe (a measuring harness has one launching thread); likewise
+// sblas_hip_debug_reload_env rewrites the switches in place and must not run beside launches of other threads.
 namespace {
 bool g_kernel_events = false;
 struct KernelEvents {
@@ -2202,6 +2227,7 @@ static void options_parse(Options &o)
         o.panel_groups = strchr(e, ',') ? atoi(strchr(e, ',') + 1) : 0;
     }
     if ((e = getenv("SBLAS_MFMA_MIN_FILL")) && *e) o.mfma_min_fill = (float)atof(e);
+    if ((e = getenv("SBLAS_VALIDATE")) && *e) o.validate = atoi(e) != 0;
     if ((e = getenv("SBLAS_TUNE")) && *e) { /* "a,b,c,d" (or "a:b:c:d"): free integers for kernel experiments */
         char buf[96];
         strncpy(buf, e, sizeof buf - 1);
@@ -2314,7 +2340,10 @@ static void panel_plan(int rows, int64_t ldbt, int &info_rows, int &groups)
 {
     if (ldbt < 64) lanes_plan(rows, (int)ldbt, info_rows, groups);
     // (128+ staged columns: two column halves per workgroup, whose accumulators leave room for two groups per wave)
-    else gen6_plan(rows, info_rows, groups, (ldbt >= 128 && options().tune[1] != 1) ? 2 : W6_GMAX);
+    // (... and so does SBLAS_SPMM_VARIANT=mfma at 64 columns: the matrix-core kernel takes panels of up to 16 rows x
+    //  MFMA_MAX_WAVES, and three groups per wave would give 132- / 144-row panels it silently leaves alone: ADVICE r2)
+    else gen6_plan(rows, info_rows, groups,
+                   ((ldbt >= 128 && options().tune[1] != 1) || options().spmm_variant == SPMM_VARIANT_MFMA) ? 2 : W6_GMAX);
 }
 
 static std::atomic<int> g_epoch{1}; // tags one call's classifier verdicts and one staging pass (see classify_panel)
@@ -2411,8 +2440,10 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
         hipLaunchKernelGGL(colrange_kernel, dim3(nparts), dim3(256), 0, s, nnz, colidx, t.parts);
     }
     const int64_t tiles = ((cols + 1 + STAGE_K - 1) / STAGE_K) * ((ldbt + 63) / 64);
+    // (a staging pass has an epoch of its own: "B holds a non-finite value" must not stick to the later column chunks of
+    //  the call, which reuse the first chunk's classifier epoch)
     hipLaunchKernelGGL(stage_range_kernel, dim3((unsigned)std::min<int64_t>(tiles, 2048)), dim3(256), 0, s, cols, n, B,
-                       ldb, Bt, ldbt, t.hdr, t.parts, nparts, epoch);
+                       ldb, Bt, ldbt, t.hdr, t.parts, nparts, g_epoch.fetch_add(1, std::memory_order_relaxed));
     *epoch_out = (classify || again) ? epoch : 0;
     return hipGetLastError();
 }
@@ -2722,15 +2753,17 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
 // device address of the panel census (the matrix-core kernel lives in another translation unit)
 unsigned long long *panel_stats_device()
 {
-    static unsigned long long *ptr[16] = {nullptr};
+    static std::atomic<unsigned long long *> ptr[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!ptr[dev]) {
+    unsigned long long *q = ptr[dev].load(std::memory_order_relaxed);
+    if (!q) {
         void *p = nullptr;
         if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_panel_stats)) != hipSuccess) return nullptr;
-        ptr[dev] = static_cast<unsigned long long *>(p);
+        q = static_cast<unsigned long long *>(p);
+        ptr[dev].store(q, std::memory_order_relaxed);
     }
-    return ptr[dev];
+    return q;
 }
 
 hipError_t panel_stats(unsigned long long out[4], bool reset)
@@ -2768,12 +2801,6 @@ hipError_t launch_merge_rowblocks(hipStream_t s, int64_t M, int64_t N, int g, co
     }
     hipLaunchKernelGGL(merge_rowblocks_kernel, dim3(capped_grid(M * N, 256)), dim3(256), 0, s, (long long)M,
                        (long long)N, g, b, alpha, beta, C, (long long)ldc);
-    return hipGetLastError();
-}
-
-hipError_t launch_sum_replicas(hipStream_t s, const ReplicaPtrs &bufs, int g, int64_t n)
-{
-    hipLaunchKernelGGL(sum_replicas_kernel, dim3(capped_grid(n, 256)), dim3(256), 0, s, bufs, g, n);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ EXPORTS = [
     "sblas_mm_read_info", "sblas_mm_read_csr", "sblas_host_fill_rand0to1",
     "sblas_hip_spmm_csr_workspace", "sblas_hip_spmm_csr", "sblas_hip_spmv_csr", "sblas_hip_axpby",
     "sblas_hip_allreduce_sum", "sblas_hip_merge_rowblocks", "sblas_partition_nnz_i64",
+    "sblas_hip_debug_validate_csr_i32",
     "sblas_hip_spmm_plan_create", "sblas_hip_spmm_plan_destroy", "sblas_hip_spmm_plan_info", "sblas_hip_spmm_csr_f64_i32_planned",
 ]
 
@@ -61,6 +62,8 @@ def lib():
     L.sblas_hip_spmm_csr_f64_i32_workspace.argtypes = [i64, i64, i64, i64]
     L.sblas_hip_spmm_csr_f64_i32.restype = C.c_int
     L.sblas_hip_spmm_csr_f64_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, f64, f64, vp, i64, vp, sz]
+    L.sblas_hip_debug_validate_csr_i32.restype = C.c_int
+    L.sblas_hip_debug_validate_csr_i32.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp]
     L.sblas_hip_spmm_plan_create.restype = C.c_int
     L.sblas_hip_spmm_plan_create.argtypes = [C.c_int, vp, i64, i64, i64, vp, vp, i64, C.POINTER(vp)]
     L.sblas_hip_spmm_plan_destroy.restype = C.c_int
@@ -281,6 +284,17 @@ def spmm_rowmajorB(rows, cols, rowptr, colidx, val, Bt, n, alpha, beta, Cmat, ld
         _dev_ptr(Bt, torch.float64, "Bt") if Bt is not None else None, ldbt, n, alpha, beta,
         _dev_ptr(Cmat, torch.float64, "C") + 8 * c_offset, ldc)
     check(rc, "sblas_hip_spmm_csr_rowmajorB_f64_i32")
+
+
+def validate_csr(rows, cols, rowptr, colidx, stream=None):
+    """True when the CSR structure on the device is well formed (sblas_hip_debug_validate_csr_i32; synchronises)."""
+    import torch
+    nnz = int(colidx.numel())
+    rc = lib().sblas_hip_debug_validate_csr_i32(-1, _stream(stream), rows, cols, nnz, _dev_ptr(rowptr, torch.int32, "rowptr"),
+                                                _dev_ptr(colidx, torch.int32, "colidx") if nnz else None)
+    if rc not in (0, 1):
+        check(rc, "sblas_hip_debug_validate_csr_i32")
+    return rc == 0
 
 
 def panel_stats(reset=True):

@@ -189,3 +189,102 @@ def test_planned_call_inside_a_hip_graph(env):
         torch.cuda.synchronize()
         assert close(C.cpu().numpy(), oracle.spmm(rows, rows, n, *A.h, Bh, np.zeros(rows * n), 2.0, 0.0)), rep
     plan.destroy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ADVICE r2 / VERDICT r2 housekeeping
+# ---------------------------------------------------------------------------------------------------------
+def test_validate_switch_refuses_column_indices_outside_the_matrix(env):
+    """The compute kernels trust the index arrays (a column index >= cols is an out-of-bounds read of the staging copy, as
+    with the vendor libraries); SBLAS_VALIDATE=1 / sblas_hip_debug_validate_csr_i32 check them first."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows = 500
+    rp, ci, v = synth.banded(rows, 20, 60)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    assert sblas.validate_csr(rows, rows, A.rowptr, A.colidx)
+    bad_ci = ci.copy()
+    bad_ci[1234] = rows + 7
+    Abad = Dev(torch, dev, rp, bad_ci, v, rows)
+    assert not sblas.validate_csr(rows, rows, Abad.rowptr, Abad.colidx)
+    bad_rp = rp.copy()
+    bad_rp[100] = bad_rp[101] + 3                                      # a row pointer that runs backwards
+    assert not sblas.validate_csr(rows, rows, torch.from_numpy(bad_rp).to(dev), A.colidx)
+    B = torch.ones(rows * 64, dtype=torch.float64, device=dev)
+    C = torch.zeros(rows * 64, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), 64) // 8, dtype=torch.float64, device=dev)
+    x, y = torch.ones(rows, dtype=torch.float64, device=dev), torch.zeros(rows, dtype=torch.float64, device=dev)
+    for setter in _env_switch("SBLAS_VALIDATE"):
+        setter("1")
+        with pytest.raises(sblas.SblasError):
+            sblas.spmm(rows, rows, Abad.rowptr, Abad.colidx, Abad.val, B, rows, 64, 1.0, 0.0, C, rows, ws)
+        with pytest.raises(sblas.SblasError):
+            sblas.spmv(rows, rows, Abad.rowptr, Abad.colidx, Abad.val, x, 1.0, 0.0, y)
+        sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, 64, 1.0, 0.0, C, rows, ws)     # a good matrix passes
+        torch.cuda.synchronize()
+    assert close(C.cpu().numpy(), oracle.spmm(rows, rows, 64, *A.h, np.ones(rows * 64), np.zeros(rows * 64), 1.0, 0.0))
+
+
+def test_nonfinite_flag_of_range_staging_does_not_stick_to_later_column_chunks(env):
+    """a row block whose call walks two column chunks through the AUTOMATIC range staging (cols >> rows; no
+    switch set).  B holds a NaN in the first chunk's columns only (in a row of the range that no nonzero refers to): the
+    first chunk's matrix-core panels fall back to the vector kernels, the second chunk's must not -- every staging pass
+    has an epoch of its own.  Block-structured rows (60 % fill) so that the matrix cores are chosen at 128 columns."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, K, n, off = 1000, 400000, 256, 200004          # (a multiple of 4: the 16 x 4 blocks stay aligned)
+    rp, ci, v = synth.block_structured(rows, nnz_per_row=150, half_band=400, fill=0.6)
+    ci = (ci + off).astype(np.int32)
+    A = Dev(torch, dev, rp, ci, v, K)
+    lo, hi = int(ci.min()), int(ci.max())
+    # a row of B that the staging pass copies (it walks whole 32-row tiles of the range) but no nonzero refers to
+    free = lo - 1 if lo % 32 else hi + 1
+    assert (free // 32 == lo // 32 or free // 32 == hi // 32) and not (lo <= free <= hi)
+    rng = np.random.default_rng(3)
+    B = torch.from_numpy(rng.standard_normal(K * n)).to(dev)
+    B.view(n, K)[5, free] = float("nan")                               # column 5: the first 128-column chunk
+    C = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+    for setter in _env_switch("SBLAS_SPMM_MAX_BT_BYTES"):
+        setter(str(450 * 1000 * 1000))                                 # a 128-column staging copy fits, 256 columns do not
+        ws = torch.full((sblas.spmm_workspace_bytes(rows, K, len(ci), n) // 8,), float("nan"), dtype=torch.float64, device=dev)
+        assert ws.numel() * 8 < 450 * 1000 * 1000
+        sblas.panel_census()
+        sblas.spmm(rows, K, A.rowptr, A.colidx, A.val, B, K, n, 1.0, 0.0, C, rows, ws)
+        torch.cuda.synchronize()
+        census = sblas.panel_census()
+    Bt = ws[: (K + 1) * 128].view(K + 1, 128)
+    assert bool(torch.isnan(Bt[: lo - 32]).all())                      # the automatic rule took the range staging
+    assert census["mfma"] > 0, census                                  # ... and the second chunk kept its matrix-core panels
+    assert census["windowed"] + census["direct"] > 0, census           # the first chunk's went to the vector kernels
+    Bh = B.cpu().numpy()
+    got = C.cpu().numpy()
+    assert np.isfinite(got).all()
+    r0 = 500
+    ref = np.zeros(rows * n)
+    oracle.spmm_rows(r0, r0 + 64, rows, K, n, *A.h, np.nan_to_num(Bh), ref, 1.0, 0.0)
+    assert close(got.reshape(n, rows)[:, r0:r0 + 64], ref.reshape(n, rows)[:, r0:r0 + 64])
+
+
+def test_forced_matrix_core_variant_keeps_panels_the_kernel_can_take(env):
+    """around 33 000 rows the panel plan picks 132- / 144-row panels (three groups per wave), which the
+    matrix-core kernel (16 rows per wave, eight waves) leaves alone; SBLAS_SPMM_VARIANT=mfma now plans two groups."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rows, n = 33000, 64
+    rp, ci, v = synth.block_structured(rows, nnz_per_row=60, half_band=300, fill=0.6)
+    A = Dev(torch, dev, rp, ci, v, rows)
+    rng = np.random.default_rng(1)
+    Bh = rng.standard_normal(rows * n)
+    B = torch.from_numpy(Bh).to(dev)
+    C = torch.zeros(rows * n, dtype=torch.float64, device=dev)
+    ws = torch.empty(sblas.spmm_workspace_bytes(rows, rows, len(ci), n) // 8, dtype=torch.float64, device=dev)
+    for setter in _env_switch("SBLAS_SPMM_VARIANT"):
+        setter("mfma")
+        sblas.panel_census()
+        sblas.spmm(rows, rows, A.rowptr, A.colidx, A.val, B, rows, n, 1.0, 0.0, C, rows, ws)
+        torch.cuda.synchronize()
+        census = sblas.panel_census()
+    assert census["mfma"] > 0 and census["windowed"] == 0, census
+    ref = np.zeros(rows * n)
+    oracle.spmm_rows(1000, 1064, rows, rows, n, *A.h, Bh, ref, 1.0, 0.0)
+    assert close(C.cpu().numpy().reshape(n, rows)[:, 1000:1064], ref.reshape(n, rows)[:, 1000:1064])

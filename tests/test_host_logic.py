@@ -294,6 +294,32 @@ def test_loader_parallel_tokenizer_matches_the_sequential_parse(sblas, tmp_path,
             sblas.read_mtx(str(bad))
 
 
+def test_loader_glued_tokens_take_the_sequential_reference_faithful_path(sblas, tmp_path, monkeypatch):
+    """fscanf lets a conversion stop inside a whitespace token ("1+2 3.5" reads i = 1, j = 2, value 3.5), so a file
+    with such tokens has fewer whitespace tokens than fields and the threaded tokenizer's chunk arithmetic does not apply:
+    it must notice (every field has to end at whitespace) and leave the file to the sequential loop -- same arrays as with
+    one thread, whatever the thread count."""
+    rng = np.random.default_rng(3)
+    M, N, NZ = 120, 97, 6000
+    entries = []
+    for k in range(NZ):
+        i, j, x = int(rng.integers(1, M + 1)), int(rng.integers(1, N + 1)), float(rng.standard_normal())
+        entries.append(("%d+%d %r" if k % 50 == 7 else "%d %d %r") % (i, j, x))      # every 50th entry: indices glued by a sign
+    path = tmp_path / "glued.mtx"
+    path.write_text("%%%%MatrixMarket matrix coordinate real general\n%d %d %d\n%s\n" % (M, N, NZ, "\n".join(entries)))
+    monkeypatch.setenv("SBLAS_LOADER_MIN_BYTES", "0")
+    out = {}
+    for threads in ("1", "5", "11"):
+        monkeypatch.setenv("SBLAS_LOADER_THREADS", threads)
+        os.utime(path, None)
+        out[threads] = sblas.read_mtx(str(path))
+    assert out["1"][2] == NZ
+    for threads in ("5", "11"):
+        assert out[threads][:4] == out["1"][:4]
+        for a, b in zip(out[threads][4:], out["1"][4:]):
+            assert a.tobytes() == b.tobytes()
+
+
 def test_partition_nnz_i64_matches_the_int32_partition(sblas):
     """CsrSparseMatrix<int64_t, T>::sync2gpu(segment) splits exactly as the int32 instantiation does (one template in
     the reference, matrix.h:356-375)."""
