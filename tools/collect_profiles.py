@@ -36,6 +36,15 @@ for op in ("spmm", "spmv"):
                              "min_ns": min(d)}
         print(op, "phases", k[:50], doc["kernels"][k])
     json.dump(doc, open(f"{dst}/{rnd}_{op}_kernel_phases.json", "w"), indent=1)
+# the other widths (method 1 on 2 / 4 / 8 GPUs hands a GPU 32 / 16 / 8 of 64 columns; configs 4 / 5 use 128 / 256) and the SpMV shapes
+for tag in ("spmm_n8", "spmm_n16", "spmm_n32", "spmm_n128", "spmm_n256", "spmv_queen", "spmv_short"):
+    f = sorted(glob.glob(f"{src}/{tag}/*/*kernel_stats.csv"), key=os.path.getmtime, reverse=True)
+    if f:
+        shutil.copy(f[0], f"{dst}/{rnd}_{tag}_kernel_stats.csv")
+    if os.path.exists(f"{src}/{tag}_bench.json") and os.path.getsize(f"{src}/{tag}_bench.json") > 10:
+        shutil.copy(f"{src}/{tag}_bench.json", f"{dst}/{rnd}_{tag}_bench.json")
+    if os.path.exists(f"{src}/{tag}.txt"):
+        shutil.copy(f"{src}/{tag}.txt", f"{dst}/{rnd}_{tag}.txt")
 for name in ("bench_default", "bench_spmv"):
     if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
         shutil.copy(f"{src}/{name}.json", f"{dst}/{rnd}_{name}.json")
@@ -84,3 +93,7 @@ merge("pmc", f"{dst}/{rnd}_hbm_traffic.json",
 merge("pmcspmv", f"{dst}/{rnd}_hbm_traffic_spmv.json",
       "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --op spmv --steps 5 --warmup 1",
       {"rows": 72000, "nnz": 28728000, "n": 1})
+for n in (8, 16, 32, 128):
+    merge("pmcn%d" % n, f"{dst}/{rnd}_hbm_traffic_n{n}.json",
+          "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --ncols %d --steps 5 --warmup 1 --cpu-seconds 0 --no-extras --no-settle" % n,
+          {"rows": 72000, "nnz": 28728000, "n": n})
