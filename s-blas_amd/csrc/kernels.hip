@@ -1075,8 +1075,11 @@ __global__ __launch_bounds__(1024) void spmm_window6_kernel(
 // group that one LDS cycle serves), and a tile row may be stored CP times over so that lanes of a group never share a
 // bank quad; measured, the kernel is bound by instruction issue, not by the LDS port -- one copy (the least tile DMA)
 // is as fast as two or four (N = 8: 0.121 / 0.122 / 0.129 ms per step, N = 16: 0.144 / 0.143), so CP = 1 ships.
-// Measured on the bench matrix (72 000 rows, 399 per row), whole step: N = 8 0.117-0.121 ms, N = 16 0.143 ms,
-// N = 32 0.204 ms (64-column path of round 2: 0.265 / 0.238 / 0.245 ms).
+// From 16 columns on two lanes may share an entry (LPE = 2: lanes k and k ^ 8 of a DPP row take the two halves of the
+// row): half the accumulators per lane, so a wave carries a group of rows more (taller panels: less tile DMA and
+// fewer prologues per row) -- N = 32: 0.206 -> 0.180 ms, N = 16: 0.139 -> 0.136.
+// Measured on the bench matrix (72 000 rows, 399 per row), whole step: N = 8 0.117-0.121 ms, N = 16 0.136-0.142 ms,
+// N = 32 0.180 ms (64-column path of round 2: 0.265 / 0.238 / 0.245 ms).
 // ---------------------------------------------------------------------------------------------
 constexpr int WL_TR = 256;          // Bt rows per LDS tile
 template <int NC, int CP> struct WlGeom {
@@ -1133,14 +1136,15 @@ typedef const __attribute__((address_space(3))) sblas_d2 *sblas_lds_d2;
 // sixteen lanes of a group then sit on sixteen different bank quads whatever rows they read.  acc[j] therefore holds
 // the column pair (j + rot) mod P.  wrap[j] = lanes whose j-th piece is past the end of the row (they read from
 // `hi` = lo - row bytes).
-template <int NC>
-__device__ __forceinline__ void lanes_fma(unsigned lo, double gv, const unsigned long long (&wrap)[NC / 2],
-                                          sblas_d2 (&acc)[NC / 2])
+// PL = pieces a lane reads of its entry's row: all P of them, or P / 2 when two lanes share an entry (NC = 32: lane k and
+// lane k ^ 8 of a DPP row take the two 128-byte halves of the row).
+template <int PL>
+__device__ __forceinline__ void lanes_fma(unsigned lo, double gv, const unsigned long long (&wrap)[PL], sblas_d2 (&acc)[PL])
 {
-    constexpr int P = NC / 2, CH = P < 4 ? P : 4;
-    const unsigned hi = lo - (unsigned)(NC * 8);
+    constexpr int CH = PL < 4 ? PL : 4;
+    const unsigned hi = lo - (unsigned)(PL * 16);
 #pragma unroll
-    for (int j0 = 0; j0 < P; j0 += CH) {
+    for (int j0 = 0; j0 < PL; j0 += CH) {
         sblas_d2 b[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -1155,6 +1159,12 @@ __device__ __forceinline__ void lanes_fma(unsigned lo, double gv, const unsigned
             acc[j0 + u].y = fma(gv, b[u].y, acc[j0 + u].y);
         }
     }
+}
+// value of lane (k ^ 8) of the same DPP row
+__device__ __forceinline__ unsigned dpp_ror8(unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); }
+__device__ __forceinline__ double dpp_ror8(double x)
+{
+    return __hiloint2double((int)dpp_ror8((unsigned)__double2hiint(x)), (int)dpp_ror8((unsigned)__double2loint(x)));
 }
 // one row of a narrow block, straight from Bt in global memory (the per-panel fallback; kept out of line and eight
 // columns at a time so that it does not set the kernel's register count): every lane takes every 64th entry, the 64
@@ -1185,7 +1195,7 @@ __device__ __noinline__ double row_direct_narrow(const int *__restrict__ colidx,
     return mine;
 }
 
-template <int NC, int CP, int G>
+template <int NC, int CP, int G, int LPE>
 __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int n, double alpha, double beta,
@@ -1194,9 +1204,11 @@ __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
 {
     using Geo = WlGeom<NC, CP>;
     constexpr int P = Geo::P;
+    constexpr int PL = P / LPE; // pieces per lane
     constexpr unsigned WL_TILE = Geo::TILE;
     constexpr int RW = 4 * G, RMAX = 12 * RW;
     static_assert(NC == 8 || NC == 16 || NC == 32, "8, 16 or 32 dense columns");
+    static_assert(LPE == 1 || (LPE == 2 && NC >= 16 && CP == 1), "two lanes per entry: 16 or 32 columns, one copy");
     static_assert(G >= 1 && G <= 3, "one to three groups of four rows per wave (counted vmcnt waits: 4 G)");
     static_assert((size_t)NC * (RMAX + 1) * sizeof(double) <= 2 * (size_t)WL_TILE, "C tile must fit in the (dead) B tiles");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1219,11 +1231,11 @@ __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
     if (tid < 64) zero_row[tid] = 0.0;
     if (tid == 0) sm_i[0] = 0;
 
-    sblas_d2 acc[G][P];
+    sblas_d2 acc[G][PL];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int j = 0; j < P; ++j) acc[g][j] = sblas_d2{0.0, 0.0};
+        for (int j = 0; j < PL; ++j) acc[g][j] = sblas_d2{0.0, 0.0};
 
     // ---- tile DMA: loader wave lw moves Bt rows 64 lw .. 64 lw + 63 of a tile, RPI rows (1 KiB of LDS) per
     // instruction: lane l fills slot l % LPR of row l / LPR with piece (l % LPR) mod P of that Bt row -- the row is stored
@@ -1254,12 +1266,17 @@ __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
 
     const int k = lane & 15, q = lane >> 4;
     // this lane's place in its LDS lane group: which copy of a tile row it reads and where in the row it starts
+    // LPE = 2: lanes k and k ^ 8 of a DPP row share an entry; lane k reads half k >> 3 of the row, starting at piece k & 7
+    // of that half (with the lane groups of ds_read_b128 -- b128_group_pos -- the sixteen lanes of a group again sit on
+    // sixteen different bank quads)
     const int gpos = b128_group_pos(lane);
-    const int rot = gpos & (P - 1), copy = (gpos / P) % CP;
-    const unsigned lane_off = (unsigned)copy * Geo::ROWB + (unsigned)rot * 16u;
-    unsigned long long wrap[P];
+    const int rot = LPE == 2 ? (k & (PL - 1)) : (gpos & (P - 1)), copy = LPE == 2 ? 0 : (gpos / P) % CP;
+    const int half = LPE == 2 ? (k >> 3) : 0;
+    const unsigned lane_off = (unsigned)copy * Geo::ROWB + (unsigned)half * (PL * 16u) + (unsigned)rot * 16u;
+    unsigned long long wrap[PL];
 #pragma unroll
-    for (int j = 0; j < P; ++j) wrap[j] = __builtin_amdgcn_ballot_w64(j + rot >= P);
+    for (int j = 0; j < PL; ++j) wrap[j] = __builtin_amdgcn_ballot_w64(j + rot >= PL);
+    const bool upper = k >= 8;
 
     const int wrow = min(row0 + wave * RW, rows);
     const int wstart = wave_uniform(rowptr[wrow]);
@@ -1308,9 +1325,23 @@ __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
                 viol |= mA ^ __builtin_amdgcn_ballot_w64(k < take);
                 viol |= mB ^ __builtin_amdgcn_ballot_w64(k + 16 < take);
                 asm volatile("s_setprio 1" ::: "memory");
-                if (mA != 0ull) lanes_fma<NC>(lb + coA, gvA, wrap, acc[g]);
-                asm volatile("" ::: "memory");
-                if (mB != 0ull) lanes_fma<NC>(lb + coB, gvB, wrap, acc[g]);
+                if constexpr (LPE == 1) {
+                    if (mA != 0ull) lanes_fma<PL>(lb + coA, gvA, wrap, acc[g]);
+                    asm volatile("" ::: "memory");
+                    if (mB != 0ull) lanes_fma<PL>(lb + coB, gvB, wrap, acc[g]);
+                } else {
+                    // four sets of eight entries per row: entry (k & 7) of the set goes to lanes k and k ^ 8
+                    const unsigned long long LOW8 = 0x00ff00ff00ff00ffull;
+                    const unsigned coAr = dpp_ror8(coA), coBr = dpp_ror8(coB);
+                    const double gvAr = dpp_ror8(gvA), gvBr = dpp_ror8(gvB);
+                    if ((mA & LOW8) != 0ull) lanes_fma<PL>(lb + (upper ? coAr : coA), upper ? gvAr : gvA, wrap, acc[g]);
+                    asm volatile("" ::: "memory");
+                    if ((mA & ~LOW8) != 0ull) lanes_fma<PL>(lb + (upper ? coA : coAr), upper ? gvA : gvAr, wrap, acc[g]);
+                    asm volatile("" ::: "memory");
+                    if ((mB & LOW8) != 0ull) lanes_fma<PL>(lb + (upper ? coBr : coB), upper ? gvBr : gvB, wrap, acc[g]);
+                    asm volatile("" ::: "memory");
+                    if ((mB & ~LOW8) != 0ull) lanes_fma<PL>(lb + (upper ? coB : coBr), upper ? gvB : gvBr, wrap, acc[g]);
+                }
                 asm volatile("s_setprio 0" ::: "memory");
                 cur[g] += take;
                 const bool more = take >= 32 && cur[g] < end[g];
@@ -1348,8 +1379,8 @@ __global__ __launch_bounds__(1024) void spmm_lanes_kernel(
             for (int g = 0; g < G; ++g) {
                 const int rr = wave * RW + 4 * g + q;
 #pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    const int pc = (j + rot) & (P - 1); // the column pair acc[g][j] holds
+                for (int j = 0; j < PL; ++j) {
+                    const int pc = half * PL + ((j + rot) & (PL - 1)); // the column pair acc[g][j] holds
                     unsafeAtomicAdd(&ctile[(2 * pc) * (RMAX + 1) + rr], acc[g][j].x);
                     unsafeAtomicAdd(&ctile[(2 * pc + 1) * (RMAX + 1) + rr], acc[g][j].y);
                 }
@@ -2310,7 +2341,7 @@ static void gen6_plan(int rows, int &info_rows, int &gen6_g, int gmax = W6_GMAX)
 static void lanes_plan(int rows, int ldbt, int &info_rows, int &groups)
 {
     const int ncu = compute_units();
-    const int gmax = ldbt <= 8 ? 3 : ldbt <= 16 ? 2 : 1;
+    const int gmax = ldbt <= 8 ? 3 : ldbt <= 16 ? (options().tune[0] == 2 ? 2 : 3) : options().tune[3] != 1 ? 2 : 1;
     long best_cost = -1;
     info_rows = 48;
     groups = 1;
@@ -2695,10 +2726,11 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    t.cls, epoch);
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
-#define SBLAS_LAUNCH_LANES(NC, CP, GG)                                                                                 \
+#define SBLAS_LAUNCH_LANES(NC, CP, GG) SBLAS_LAUNCH_LANES4(NC, CP, GG, 1)
+#define SBLAS_LAUNCH_LANES4(NC, CP, GG, LPE)                                                                           \
     do {                                                                                                              \
-        raise_dynamic_lds((const void *)spmm_lanes_kernel<NC, CP, GG>, WlGeom<NC, CP>::LDS_BYTES);                    \
-        hipLaunchKernelGGL((spmm_lanes_kernel<NC, CP, GG>), dim3((unsigned)np), dim3(1024), (WlGeom<NC, CP>::LDS_BYTES), s, \
+        raise_dynamic_lds((const void *)spmm_lanes_kernel<NC, CP, GG, LPE>, WlGeom<NC, CP>::LDS_BYTES);               \
+        hipLaunchKernelGGL((spmm_lanes_kernel<NC, CP, GG, LPE>), dim3((unsigned)np), dim3(1024), (WlGeom<NC, CP>::LDS_BYTES), s, \
                            rows, cols, np, rowptr, colidx, val, Bt, n, alpha, beta, C, ldc, t.hdr, t.info, t.cls,      \
                            info_rows, (int)nnz);                                                                      \
     } while (0)
@@ -2710,11 +2742,15 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                 else { if (g == 3) SBLAS_LAUNCH_LANES(8, 1, 3); else if (g == 2) SBLAS_LAUNCH_LANES(8, 1, 2); else SBLAS_LAUNCH_LANES(8, 1, 1); }
             } else if (ldbt == 16) {
                 if (cp == 2) { if (g == 2) SBLAS_LAUNCH_LANES(16, 2, 2); else SBLAS_LAUNCH_LANES(16, 2, 1); }
+                else if (g == 3) SBLAS_LAUNCH_LANES4(16, 1, 3, 2);   // two lanes per entry: eight accumulators per lane and group
                 else { if (g == 2) SBLAS_LAUNCH_LANES(16, 1, 2); else SBLAS_LAUNCH_LANES(16, 1, 1); }
             } else {
-                SBLAS_LAUNCH_LANES(32, 1, 1);
+                // 32 columns: two lanes per entry (sixteen accumulators per lane: two groups of rows per wave fit), or a
+                // lane per entry with one group (SBLAS_TUNE=*,*,*,1: A/B runs)
+                if (g == 2) SBLAS_LAUNCH_LANES4(32, 1, 2, 2); else if (opt.tune[3] == 1) SBLAS_LAUNCH_LANES(32, 1, 1); else SBLAS_LAUNCH_LANES4(32, 1, 1, 2);
             }
 #undef SBLAS_LAUNCH_LANES
+#undef SBLAS_LAUNCH_LANES4
             if (kev) {
                 (void)hipEventRecord(kev->b, s);
                 kev->recorded = true;

@@ -150,7 +150,8 @@ def test_narrow_mixed_panels_row_block_and_padding(env, n):
     assert (got[:, :100] == Cbig.reshape(n, rows)[:, :100]).all() and (got[:, 400:] == Cbig.reshape(n, rows)[:, 400:]).all()
 
 
-@pytest.mark.parametrize("n,setting", [(8, "48,1"), (8, "96,2"), (8, "144,3"), (16, "48,1"), (16, "96,2"), (32, "48,1")])
+@pytest.mark.parametrize("n,setting", [(8, "48,1"), (8, "96,2"), (8, "144,3"), (16, "48,1"), (16, "96,2"), (16, "144,3"), (32, "48,1"),
+                                       (32, "96,2")])
 def test_narrow_census_and_every_panel_height(env, panel_rows_env, n, setting):
     """Every instantiated (width, groups per wave) pair; the census tells an LDS-tiled run from a fallback or a direct
     one ([windowed, direct, fallback])."""
@@ -183,13 +184,13 @@ def test_narrow_census_and_every_panel_height(env, panel_rows_env, n, setting):
     assert run(rp4, ci4, v4, rows, rows) == (10, 0, 0)
 
 
-@pytest.mark.parametrize("n,copies", [(8, 2), (8, 4), (16, 2)])
-def test_narrow_tile_rows_stored_more_than_once(env, tune_env, n, copies):
+@pytest.mark.parametrize("n,copies,tune", [(8, 2, "2,0,0,0"), (8, 4, "4,0,0,0"), (16, 2, "2,0,0,0"), (32, 1, "0,0,0,1")])
+def test_narrow_tile_rows_stored_more_than_once(env, tune_env, n, copies, tune):
     """SBLAS_TUNE=<copies>: the LDS tile holds every Bt row `copies` times over (bank-conflict experiment, kept
-    instantiated): same results."""
+    instantiated); SBLAS_TUNE=0,0,0,1: 32 columns with a lane per entry instead of two lanes per entry: same results."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
-    tune_env("%d,0,0,0" % copies)
+    tune_env(tune)
     rows = 900
     rp, ci, v = synth.banded(rows, 70, 300)
     A = Dev(torch, dev, rp, ci, v, rows)
