@@ -76,7 +76,7 @@ def one_case(case, rng, dev, max_rows):
     m = b - a
     sub_rp = rp[a:b + 1] - rp[a]
     sub_ci, sub_v = ci[rp[a]:rp[b]], v[rp[a]:rp[b]]
-    n = int(rng.choice([1, 2, 5, 8, 9, 17, 32, 33, 64, 65, 100, 128, 130, 200, 256, 300]))
+    n = int(rng.choice([1, 2, 5, 8, 9, 12, 16, 17, 24, 32, 33, 64, 65, 100, 128, 130, 200, 256, 300]))
     ldb = cols + int(rng.choice([0, 0, 3]))
     M_full = rows
     ldc = M_full + int(rng.choice([0, 0, 5]))
