@@ -1,4 +1,4 @@
-# A/B of library builds on one box: tools/r3_ab.sh <ncols> lib1 lib2 ... (files under gpurun_ab/), two interleaved rounds
+# A/B of library builds on one box: tools/ab_libs.sh <ncols> lib1 lib2 ... (files under gpurun_ab/), two interleaved rounds
 cd $GRAFT_REPO_ROOT
 n=$1; shift
 cp s-blas_amd/lib/libsblas_hip.so /tmp/orig.so
