@@ -1195,8 +1195,13 @@ __device__ __noinline__ double row_direct_narrow(const int *__restrict__ colidx,
     return mine;
 }
 
+// 8 columns, one group of rows per wave: 63 registers and 33 KB of LDS, so TWO workgroups share a CU -- one's prologue and
+// epilogue (a fifth of a panel's time at this width) run under the other's tile loop, eight waves per SIMD hide the LDS
+// and window round trips: 48-row panels this way 0.117-0.118 ms per step against 0.124 with one workgroup of 144-row
+// panels per CU (and 0.134 with one workgroup of 48-row panels).  At 16 columns (two lanes per entry, spills at 64
+// registers) the same bought 1 %: not kept.
 template <int NC, int CP, int G, int LPE>
-__global__ __launch_bounds__(1024) void spmm_lanes_kernel(
+__global__ __launch_bounds__(1024, (NC == 8 && CP == 1 && G == 1) ? 8 : 4) void spmm_lanes_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int2 *__restrict__ info,
@@ -2345,7 +2350,8 @@ static void lanes_plan(int rows, int ldbt, int &info_rows, int &groups)
     long best_cost = -1;
     info_rows = 48;
     groups = 1;
-    for (int g = 1; g <= gmax; ++g)
+    // 8 columns: one group of rows per wave, two workgroups per CU (see spmm_lanes_kernel); SBLAS_SPMM_PANEL_ROWS overrides
+    for (int g = 1; g <= gmax && ldbt > 8; ++g)
         for (int r = 12 * 4 * g; r >= 4 * 4 * g; r -= 4 * g) {
             if (r < SPMM_MIN_PANEL_ROWS) continue;
             const long panels = (rows + r - 1) / r;
