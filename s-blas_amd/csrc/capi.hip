@@ -256,7 +256,7 @@ static int spmm_impl(int dev, void *stream, int64_t rows, int64_t cols, int64_t 
             range_ldbt = ldbt;
         } else if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
             spmm_variant() != sblas::SPMM_VARIANT_LANES &&
-            (ldbt >= 64 || (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE &&
+            (ldbt >= 64 || (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && sblas::narrow_classify_worthwhile(rows, nnz, ldbt) &&
                             ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull <= 0xffffffffull)) &&
             cols > 0 && nnz > 0 && ldb >= cols && ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
@@ -299,6 +299,7 @@ int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols
     const int64_t w = spmm_chunk_cols(cols, n);
     const int64_t ldbt = chunk_ldbt(cols, n, n < w ? n : w);
     if (ldbt < 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_OK; // 64-bit narrow kernels: unplanned
+    if (!sblas::narrow_classify_worthwhile(rows, nnz, ldbt)) return SBLAS_OK; // short rows at a narrow width: nothing is classified
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }
     if (hipMalloc(&p->buf, sblas::plan_tail_bytes(rows)) != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }

@@ -79,6 +79,7 @@ struct PlanView {
     int nparts = 0;
 };
 size_t plan_tail_bytes(int64_t rows);
+bool narrow_classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt);
 hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx, int64_t ldbt,
                       int variant, bool use_range, PlanView *pv);
 hipError_t launch_stage_planned(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,

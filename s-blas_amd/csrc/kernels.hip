@@ -316,7 +316,7 @@ constexpr size_t W2_LDS_BYTES = (2 * (size_t)W2_TILE + 64) * sizeof(double) + 64
 constexpr int MFMA_BITMAP_WORDS = 1024; // 32768 blocks = 131072 columns of span
 __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int npanels, int panel_rows,
                                                const int *__restrict__ rowptr, const int *__restrict__ colidx,
-                                               int max_row_len, float min_density, float mfma_min_fill,
+                                               int max_row_len, float min_density, float min_rowlen, float mfma_min_fill,
                                                int merge_probe, int *__restrict__ tail, int2 *__restrict__ info,
                                                int *__restrict__ cls, int epoch, unsigned *__restrict__ bitmap)
 {
@@ -344,7 +344,10 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         mlen = max(mlen, __shfl_xor(mlen, m, WAVE));
     }
     const bool sane = last >= first && first >= 0 && last < cols; // (first / last of sorted rows; the kernels re-check)
-    bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1);
+    // (narrow widths: a visit of the lane-per-entry kernel costs the same whether a row has 5 or 30 entries in the tile, so
+    //  short rows stay with the direct kernels: min_rowlen = nonzeros per row the panel must average)
+    bool window_ok = sane && mlen <= max_row_len && (float)nnz >= min_density * (float)(last - first + 1) &&
+                     (float)nnz >= min_rowlen * (float)min(panel_rows, rows - p * panel_rows);
     // Do the rows come in groups that list the same columns (the unknowns of one mesh node in a multi-dof FEM matrix),
     // and is the group length a multiple of three (3-dof nodes; six dofs are two groups of three)?  Neighbouring rows
     // at the panel's head are compared entry by entry: the first pair that differs ends the (possibly cut) group the
@@ -486,13 +489,13 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
 __global__ __launch_bounds__(256) void classify_panels_kernel(int rows, int cols, int npanels, int panel_rows,
                                                              const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx, int max_row_len,
-                                                             float min_density, float mfma_min_fill, int merge_probe,
+                                                             float min_density, float min_rowlen, float mfma_min_fill, int merge_probe,
                                                              int *__restrict__ tail, int2 *__restrict__ info,
                                                              int *__restrict__ cls, int epoch)
 {
     __shared__ unsigned bitmap[4][MFMA_BITMAP_WORDS];
     classify_panel(blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx, max_row_len,
-                   min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch, bitmap[threadIdx.x >> 6]);
+                   min_density, min_rowlen, mfma_min_fill, merge_probe, tail, info, cls, epoch, bitmap[threadIdx.x >> 6]);
 }
 // Stage 1 and the panel classifier in one launch (the fused C-ABI entry: both depend only on the call's inputs, and
 // the classifier's dependent loads hide behind the staging traffic): the first ceil(npanels / 4) workgroups
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                                                             int stage_blocks, int rows, int npanels, int panel_rows,
                                                             const int *__restrict__ rowptr,
                                                             const int *__restrict__ colidx, int max_row_len,
-                                                            float min_density, float mfma_min_fill, int merge_probe,
+                                                            float min_density, float min_rowlen, float mfma_min_fill, int merge_probe,
                                                             int *__restrict__ tail, int2 *__restrict__ info,
                                                             int *__restrict__ cls, int epoch)
 {
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void stage_classify_kernel(int64_t cols, int64
                    ldbt, tail, epoch);
     } else if (blockIdx.y == 0) {
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
-                       max_row_len, min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch,
+                       max_row_len, min_density, min_rowlen, mfma_min_fill, merge_probe, tail, info, cls, epoch,
                        reinterpret_cast<unsigned *>(&tile[0][0]) + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
     }
 }
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void colrange_classify_kernel(int64_t nnz, int
                                                                int cols, int npanels, int panel_rows,
                                                                const int *__restrict__ rowptr,
                                                                const int *__restrict__ colidx, int max_row_len,
-                                                               float min_density, float mfma_min_fill, int merge_probe,
+                                                               float min_density, float min_rowlen, float mfma_min_fill, int merge_probe,
                                                                int *__restrict__ tail, int2 *__restrict__ info,
                                                                int *__restrict__ cls, int epoch)
 {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(256) void colrange_classify_kernel(int64_t nnz, int
         colrange_part(nnz, colidx, part, (int)blockIdx.x - cblocks, nparts, reinterpret_cast<int2 *>(bitmaps));
     else
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, cols, npanels, panel_rows, rowptr, colidx,
-                       max_row_len, min_density, mfma_min_fill, merge_probe, tail, info, cls, epoch,
+                       max_row_len, min_density, min_rowlen, mfma_min_fill, merge_probe, tail, info, cls, epoch,
                        bitmaps + (threadIdx.x >> 6) * MFMA_BITMAP_WORDS);
 }
 // ... and for narrow blocks (no matrix cores, no row-merging probe there)
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256) void stage_classify_narrow_kernel(int64_t cols
                                                                    int npanels, int panel_rows,
                                                                    const int *__restrict__ rowptr,
                                                                    const int *__restrict__ colidx, int max_row_len,
-                                                                   float min_density, int *__restrict__ tail,
+                                                                   float min_density, float min_rowlen, int *__restrict__ tail,
                                                                    int2 *__restrict__ info, int *__restrict__ cls,
                                                                    int epoch)
 {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(256) void stage_classify_narrow_kernel(int64_t cols
         stage_rows_narrow<NC>((int64_t)((int)blockIdx.x - cblocks) * 256, cols, n, B, ldb, Bt, tail, epoch);
     else
         classify_panel((int)blockIdx.x * 4 + (threadIdx.x >> 6), rows, (int)cols, npanels, panel_rows, rowptr, colidx,
-                       max_row_len, min_density, 2.0f, 0, tail, info, cls, epoch, nullptr);
+                       max_row_len, min_density, min_rowlen, 2.0f, 0, tail, info, cls, epoch, nullptr);
 }
 // The stage-2 kernels run one after the other, so a matrix whose panels split between the matrix-core kernel and the
 // vector kernels pays for two half-empty launches (block-structured rows at the fill threshold, N = 128: 1.05 ms against
@@ -2420,6 +2423,26 @@ size_t workspace_tail_bytes(int64_t rows)
 // kernel wins by 36 %, at 2.1-2.4 the two are within 5 %, from 2.75 on the LDS-tiled kernel wins (6 % ... 70 % at 6 uses,
 // where round 1's bar stood).
 static float window_min_density(int panel_rows) { return options().window_density * (float)panel_rows / 16.0f; }
+// Nonzeros per row a panel must average to take the narrow LDS-tiled kernel (0 at 64+ staged columns).  Measured on banded rows
+// (tools/spmm_shapes.py banded:ROWS:PERROW:HALFBAND, 1 M rows) against the kernels that take the panel otherwise:
+// gpurun_out/r3_narrow_shapes*.txt, DESIGN 3.9.
+// (declared in kernels.h) A narrow call whose rows average less than three quarters of the bar does not classify at all: the classifier,
+// an LDS-tiled launch that every workgroup leaves at once and the per-row ownership test of the direct kernel cost a
+// 1 M-row matrix of 5 nonzeros per row 0.23 ms of a 0.09 ms product (N = 8).
+static float window_min_rowlen(int64_t ldbt);
+bool narrow_classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt)
+{
+    return ldbt >= 64 || (rows > 0 && (double)nnz >= 0.75 * (double)window_min_rowlen(ldbt) * (double)rows);
+}
+static float window_min_rowlen(int64_t ldbt)
+{
+    const int t = options().tune[1];
+    if (ldbt >= 64) return 0.0f;
+    if (t > 1) return (float)t; /* SBLAS_TUNE=*,<nonzeros per row>: threshold sweeps */
+    // banded rows, 1 M rows, LDS-tiled kernel | lane groups (ms): N = 8: 27 per row .418 | .283, 40: .464 | .377, 60: .524 | .547,
+    // 80: .466 | .554; N = 16: 10: .452 | .287, 27: .483 | .540; N = 32: 10: .672 | .553, 27: .711 | 1.04
+    return ldbt <= 8 ? 56.0f : ldbt <= 16 ? 20.0f : 16.0f;
+}
 static float mfma_min_fill(int variant, int panel_rows, int64_t ldbt)
 {
     if (panel_rows > 16 * MFMA_MAX_WAVES) return 2.0f; // the matrix-core kernel runs one wave per 16 rows of a panel
@@ -2470,7 +2493,7 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
         panel_plan(rows, ldbt, info_rows, g);
         const int np = (rows + info_rows - 1) / info_rows;
         hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
-                           nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows),
+                           nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt),
                            mfma_min_fill(variant, info_rows, ldbt), (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr,
                            t.info, t.cls, epoch);
     } else if (!again) {
@@ -2500,7 +2523,7 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
         const dim3 ngrid((unsigned)((cols + 1 + 255) / 256 + (np + 3) / 4));
 #define SBLAS_STAGE_NARROW(NC)                                                                                         \
     hipLaunchKernelGGL(stage_classify_narrow_kernel<NC>, ngrid, dim3(256), 0, s, cols, n, B, ldb, Bt, rows, np, info_rows, \
-                       rowptr, colidx, 1 << 24, window_min_density(info_rows), t.hdr, t.info, t.cls, epoch)
+                       rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt), t.hdr, t.info, t.cls, epoch)
         if (ldbt == 8) SBLAS_STAGE_NARROW(8);
         else if (ldbt == 16) SBLAS_STAGE_NARROW(16);
         else SBLAS_STAGE_NARROW(32);
@@ -2510,7 +2533,7 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     }
     dim3 grid((unsigned)(stage_blocks + (np + 3) / 4), (unsigned)((ldbt + 63) / 64));
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
-                       info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows),
+                       info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt),
                        ldbt < 64 ? 2.0f : mfma_min_fill(variant, info_rows, ldbt),
                        (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
     *epoch_out = epoch;
@@ -2539,11 +2562,11 @@ hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int 
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 4095) / 4096, TAIL_PARTS));
     if (use_range)
         hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
-                           nparts, rows, cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), fill,
+                           nparts, rows, cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt), fill,
                            probe, t.hdr, t.info, t.cls, epoch);
     else
         hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np, info_rows,
-                           rowptr, colidx, 1 << 24, window_min_density(info_rows), fill, probe, t.hdr, t.info, t.cls, epoch);
+                           rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt), fill, probe, t.hdr, t.info, t.cls, epoch);
     if (ldbt >= 128)
         hipLaunchKernelGGL(mfma_vote_kernel, dim3(1), dim3(1024), 0, s, np, t.hdr, t.info, t.cls, epoch,
                            variant == SPMM_VARIANT_MFMA ? 1 : 0);
@@ -2629,7 +2652,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    info_rows, rowptr, colidx, /* 32-bit buffer offsets inside a wave's rows */ 1 << 24,
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
-                                   window_min_density(info_rows), mfma_min_fill(variant, info_rows, ldbt),
+                                   window_min_density(info_rows), window_min_rowlen(ldbt), mfma_min_fill(variant, info_rows, ldbt),
                                    (ldbt >= 128 && opt.direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
             // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)
@@ -2716,7 +2739,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         // the 16- / 32-column direct kernel addresses Bt with 32-bit byte offsets
         const bool wide_offsets = ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull;
         const bool classified = pv || (!wide_offsets && variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
-                                       variant != SPMM_VARIANT_LANES);
+                                       variant != SPMM_VARIANT_LANES && (pre_epoch != 0 || narrow_classify_worthwhile(rows, nnz, ldbt)));
         const bool preclassified = pv || (pre_epoch != 0 && classified);
         const int epoch = pv ? pv->epoch : preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         const int *cls = nullptr;
@@ -2728,7 +2751,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             const int np = (rows + info_rows - 1) / info_rows;
             if (!preclassified)
                 hipLaunchKernelGGL(classify_panels_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, rows, cols, np,
-                                   info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), 2.0f, 0, t.hdr, t.info,
+                                   info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt), 2.0f, 0, t.hdr, t.info,
                                    t.cls, epoch);
             KernelEvents *kev = kernel_events_slot();
             if (kev) (void)hipEventRecord(kev->a, s);
@@ -2764,8 +2787,12 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             cls = t.cls;
         }
         const unsigned panels = (unsigned)((rows + PANEL_ROWS - 1) / PANEL_ROWS);
+        // short rows leave most of a row-per-wave sweep empty: lane groups below 24 / 16 nonzeros per row on average at 16 / 32
+        // columns (banded rows of 5 / 10 per row, 1 M rows: N = 16 0.214 / 0.287 ms against 0.585 / 0.667 row per wave; N = 32
+        // 0.403 / 0.553 against 0.691 / 0.758; from 27 per row on the row-per-wave kernel wins)
+        const bool short_rows = ldbt >= 16 && avg_row < (ldbt == 16 ? 24.0 : 16.0) && variant != SPMM_VARIANT_DIRECT_DPP;
         if (!need_direct) {
-        } else if (ldbt >= 16 && !wide_offsets && variant != SPMM_VARIANT_LANES) {
+        } else if (ldbt >= 16 && !wide_offsets && variant != SPMM_VARIANT_LANES && !short_rows) {
             // the row-per-wave kernel, four nonzeros per instruction: sixteen lanes x 16 bytes per nonzero (with 16 staged
             // columns the upper eight lanes of a DPP row read past the Bt row, into columns that are never stored)
             const int wide_panels = (rows + WIDE_PANEL - 1) / WIDE_PANEL;

@@ -52,7 +52,7 @@ def test_narrow_banded_every_width_and_selection(env, variant_env, variant, n):
     from sblas_amd import synth
     variant_env(variant)
     rows = 1100
-    rp, ci, v = synth.banded(rows, 45, 330, seed=n)
+    rp, ci, v = synth.banded(rows, 70, 330, seed=n)                  # (the narrow kernel takes panels from 56 / 20 / 16 nonzeros per row on)
     A = Dev(torch, dev, rp, ci, v, rows)
     rng = np.random.default_rng(n)
     B, C0 = rng.standard_normal(rows * n), rng.standard_normal(rows * n)
@@ -74,7 +74,7 @@ def test_narrow_fallback_on_unsorted_rows(env, n, damage):
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
     rows = 600
-    rp, ci, v = synth.banded(rows, 50, 120 if n == 16 else 400)      # rows inside one 256-row tile / across several
+    rp, ci, v = synth.banded(rows, 70, 120 if n == 16 else 400)      # rows inside one 256-row tile / across several
     ci, v = ci.copy(), v.copy()
     rng = np.random.default_rng(11)
     if damage == "all_descending":
@@ -171,15 +171,17 @@ def test_narrow_census_and_every_panel_height(env, panel_rows_env, n, setting):
         return st
 
     rows = 10 * pr - 7                                                    # the last panel is short
-    rp, ci, v = synth.banded(rows, 60, 400)                               # rows span three or four 256-row tiles
+    rp, ci, v = synth.banded(rows, 70, 400)                               # rows span three or four 256-row tiles
     assert run(rp, ci, v, rows, rows) == (10, 0, 0)                       # every panel through LDS
     ci2, v2 = ci.copy(), v.copy()
     r = 2 * pr + 4                                                        # (far from the matrix edges: a full-width row)
     ci2[rp[r]:rp[r + 1]] = ci2[rp[r]:rp[r + 1]][::-1]                     # one descending row in panel 2
     v2[rp[r]:rp[r + 1]] = v2[rp[r]:rp[r + 1]][::-1]
     assert run(rp, ci2, v2, rows, rows) == (9, 0, 1)                      # that panel recomputed, the others not
-    rp3, ci3, v3 = synth.random_csr(rows, 5000, 6, seed=3, sorted_rows=True)
+    rp3, ci3, v3 = synth.random_csr(rows, 5000, 60, seed=3, sorted_rows=True)
     assert run(rp3, ci3, v3, rows, 5000) == (0, 10, 0)                    # too sparse over its span: direct kernel
+    rp5, ci5, v5 = synth.random_csr(rows, 5000, 4, seed=3, sorted_rows=True)
+    assert run(rp5, ci5, v5, rows, 5000) == (0, 0, 0)                     # rows far below the bar: the call does not classify at all
     rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows of 500: several windows per tile visit
     assert run(rp4, ci4, v4, rows, rows) == (10, 0, 0)
 
@@ -207,7 +209,7 @@ def test_narrow_nonfinite_b_rows_not_referenced_stay_out(env, variant_env, n):
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
     rows = 700
-    rp, ci, v = synth.banded(rows, 21, 60)
+    rp, ci, v = synth.banded(rows, 64, 200)
     ci = ci.copy()
     ci[ci == 0] = 1
     ci[ci % 5 == 3] += 1                              # nobody refers to columns = 3 (mod 5) ...

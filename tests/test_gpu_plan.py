@@ -35,7 +35,7 @@ def _shapes(synth):
             ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(3000, mixed_lens[r], replace=False))
     mixed = (rp.astype(np.int32), ci, rng.standard_normal(rp[-1]))
     return {
-        "banded": (synth.banded(1500, 60, 300), 1500),                       # every panel through LDS
+        "banded": (synth.banded(1500, 80, 300), 1500),                       # every panel through LDS
         "sparse": (synth.random_csr(1000, 4000, 7, seed=3, sorted_rows=True, empty_every=9), 4000),   # every panel direct
         "mixed": (mixed, 3000),                                              # both
         "grid": (synth.queen_like_grid(3000, half_band=400), 3000),          # rows in groups of three: row merging at 128+
@@ -57,7 +57,8 @@ def test_planned_call_is_bit_identical_and_launches_only_what_has_panels(env, sh
     ws = torch.empty(sblas.spmm_workspace_bytes(rows, cols, len(ci), n) // 8, dtype=torch.float64, device=dev)
     plan = sblas.SpmmPlan(rows, cols, A.rowptr, A.colidx, n)
     info = plan.info()
-    assert info["active"] and info["ldbt"] == int(sblas.lib().sblas_hip_spmm_ldbt(n))
+    short_rows_narrow = shape == "sparse" and n <= 32              # such a call classifies nothing: nothing to plan either
+    assert info["active"] == (not short_rows_narrow) and (short_rows_narrow or info["ldbt"] == int(sblas.lib().sblas_hip_spmm_ldbt(n)))
     for alpha, beta in ((1.5, -0.5), (1.0, 0.0)):
         Cu = torch.from_numpy(C0.copy()).to(dev)
         Cp = torch.from_numpy(C0.copy()).to(dev)
@@ -76,7 +77,7 @@ def test_planned_call_is_bit_identical_and_launches_only_what_has_panels(env, sh
     assert (info["mfma"] > 0) == (cp["mfma"] > 0), (info, cp)
     if shape == "banded":
         assert info["direct"] == 0 and info["windowed"] > 0
-    if shape == "sparse":
+    if shape == "sparse" and not short_rows_narrow:
         assert info["windowed"] == 0 and info["direct"] > 0
     if shape == "grid" and n >= 128:
         assert info["merge"]
