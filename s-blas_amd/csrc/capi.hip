@@ -247,7 +247,8 @@ static int spmm_impl(int dev, void *stream, int64_t rows, int64_t cols, int64_t 
             if (scope.err != hipSuccess) return SBLAS_E_HIP;
             const bool direct_only = spmm_variant() == sblas::SPMM_VARIANT_DIRECT_DPP ||
                                      spmm_variant() == sblas::SPMM_VARIANT_DIRECT_ROWS ||
-                                     spmm_variant() == sblas::SPMM_VARIANT_DIRECT_MERGE;
+                                     spmm_variant() == sblas::SPMM_VARIANT_DIRECT_MERGE ||
+                                     !sblas::classify_worthwhile(rows, nnz, ldbt);
             pre_epoch = (!direct_only && ldbt == range_ldbt) ? range_epoch : 0;
             if (sblas::launch_stage_range((hipStream_t)stream, cols, nj, B + j0 * ldb, ldb, Bt, ldbt, (int)rows, nnz,
                                           rowptr, colidx, spmm_variant(), direct_only ? 0 : 1, &pre_epoch) != hipSuccess)
@@ -256,7 +257,8 @@ static int spmm_impl(int dev, void *stream, int64_t rows, int64_t cols, int64_t 
             range_ldbt = ldbt;
         } else if (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_DPP && spmm_variant() != sblas::SPMM_VARIANT_DIRECT_ROWS &&
             spmm_variant() != sblas::SPMM_VARIANT_LANES &&
-            (ldbt >= 64 || (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE && sblas::narrow_classify_worthwhile(rows, nnz, ldbt) &&
+            sblas::classify_worthwhile(rows, nnz, ldbt) &&
+            (ldbt >= 64 || (spmm_variant() != sblas::SPMM_VARIANT_DIRECT_MERGE &&
                             ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull <= 0xffffffffull)) &&
             cols > 0 && nnz > 0 && ldb >= cols && ldbt_ok(ldbt, nj)) {
             // default path: the panel classifier rides in the staging launch (one launch and one gap less per call)
@@ -299,7 +301,7 @@ int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols
     const int64_t w = spmm_chunk_cols(cols, n);
     const int64_t ldbt = chunk_ldbt(cols, n, n < w ? n : w);
     if (ldbt < 64 && ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull) return SBLAS_OK; // 64-bit narrow kernels: unplanned
-    if (!sblas::narrow_classify_worthwhile(rows, nnz, ldbt)) return SBLAS_OK; // short rows at a narrow width: nothing is classified
+    if (!sblas::classify_worthwhile(rows, nnz, ldbt)) return SBLAS_OK; // short rows at a width of 64 columns or fewer: nothing is classified
     DeviceScope scope(dev);
     if (scope.err != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }
     if (hipMalloc(&p->buf, sblas::plan_tail_bytes(rows)) != hipSuccess) { delete p; *plan_out = nullptr; return SBLAS_E_HIP; }

@@ -32,11 +32,13 @@ enum { TAIL_NONFINITE = 0,    // = TAIL_STAGE_EPOCH's value when the staging pas
        TAIL_MFMA_EPOCH = 4,   // epoch of the classifier run that gave panels to the matrix-core kernel
        TAIL_MERGE_EPOCH = 6,  // epoch of the call whose direct panels go to the row-merging kernel (rows share column patterns)
        TAIL_MFMAD_EPOCH = 5,  // ... and some of them fall back to the DIRECT kernel when B holds a non-finite value
+       TAIL_ROWS_EPOCH = 7,   // epoch of the call whose direct panels go to the four-rows-per-wave kernel (128+ staged columns)
        TAIL_HDR = 16 };
 constexpr int TAIL_PARTS = 1024; // (min, max) column pairs of the column-range pass of a row block (behind the header)
 enum { PANEL_DIRECT = 0, PANEL_WINDOW = 1, PANEL_MFMA_W = 2, PANEL_MFMA_D = 3,
        PANEL_CLASS_MASK = 0xff, PANEL_SHARED_ROWS = 0x100 /* flag: the panel's leading rows list the same columns */,
-       PANEL_PHASE_SHIFT = 9 /* two bits: (row index where a group of three such rows starts) mod 3 */ };
+       PANEL_PHASE_SHIFT = 9 /* two bits: (row index where a group of three such rows starts) mod 3 */,
+       PANEL_WAVE_ROWS = 0x800 /* flag: columns in runs, or row lengths far apart: a row per wave suits the panel */ };
 constexpr int MFMA_MAX_WAVES = 8; // 16 rows per wave: panels of up to 128 rows (taller panels never take the MFMA kernel)
 size_t workspace_tail_bytes(int64_t rows);
 unsigned long long *panel_stats_device();
@@ -75,11 +77,12 @@ struct PlanView {
     int info_rows = 0, groups = 0;
     long n_window = 0, n_direct = 0, n_mfma_w = 0, n_mfma_d = 0; // panels per class after the votes
     bool merge = false;         // the call's direct panels go to the row-merging kernel
+    bool four_rows = false;     // ... to the four-rows-per-wave kernel (128+ staged columns)
     bool use_range = false;     // stage only the column range [lo, hi] of B
     int nparts = 0;
 };
 size_t plan_tail_bytes(int64_t rows);
-bool narrow_classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt);
+bool classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt);
 hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx, int64_t ldbt,
                       int variant, bool use_range, PlanView *pv);
 hipError_t launch_stage_planned(hipStream_t s, int64_t cols, int64_t n, const double *B, int64_t ldb, double *Bt,

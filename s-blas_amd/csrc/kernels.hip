@@ -361,7 +361,7 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
     bool shared = false;
     int phase = 0;
     const bool strong = window_ok && (float)nnz >= (float)panel_rows / 16.0f * (float)(last - first + 1);
-    if (sane && !strong && merge_probe) {
+    if (sane && !strong && (merge_probe & 1)) {
         const int r0 = p * panel_rows;
         int start = -1, len = 0; // first row of the measured group (relative to r0), rows counted so far
         for (int k = 0; k < 12; ++k) {
@@ -393,6 +393,7 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
     // blocks it touches (entries / (4 x distinct blocks)), and that takes one pass over one row.
     // the longest of the panel's first 16 rows (the first row itself may be empty): its length and the number of
     // distinct 4-column blocks it touches, one pass over one row
+    int head_adj = 0; // entries of that row whose column follows its predecessor's
     auto head_row = [&](int &len_out, int &runs_out) {
         const int r0 = p * panel_rows, r1 = min(min(r0 + 16, r0 + panel_rows), rows);
         int slen = 0, srow = r0;
@@ -403,15 +404,20 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
         srow = r0 + 15 - (__builtin_amdgcn_readfirstlane(key) & 15);
         srow = min(srow, r1 - 1);
         const int a0 = rowptr[srow], b0 = rowptr[srow + 1];
-        int runs = 0;
+        int runs = 0, adj = 0;
         for (int e = a0 + lane; e < b0; e += WAVE) {
             const int c = colidx[e], cp = e > a0 ? colidx[e - 1] : -8;
             runs += (c >> 2) != (cp >> 2);
+            adj += c == cp + 1;
         }
 #pragma unroll
-        for (int m = 32; m > 0; m >>= 1) runs += __shfl_xor(runs, m, WAVE);
+        for (int m = 32; m > 0; m >>= 1) {
+            runs += __shfl_xor(runs, m, WAVE);
+            adj += __shfl_xor(adj, m, WAVE);
+        }
         len_out = b0 - a0;
         runs_out = runs;
+        head_adj = adj;
     };
     // Rows whose columns come in runs (mesh numberings: nine consecutive columns per neighbour plane) are served well
     // out of the L2 by the direct kernels, so the LDS-tiled kernel pays later on them: grid-structured rows at 64
@@ -471,10 +477,21 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
                    (float)(e1 - e0) >= need * (float)(r1 - r0) * 4.0f * (float)nblk;
         }
     }
+    // Which direct kernel (128+ staged columns; the vote below decides for the matrix)?  Four rows per wave on 64-column
+    // tiles beat a row per wave on 128-column tiles on banded rows of any length (N = 256, 1 M rows, 32 / 64 / 100 per
+    // row: 4.17 / 6.82 / 10.1 ms against 5.20 / 7.14 / 11.3), but not where a row's columns come in runs (Queen-like rows,
+    // clusters of three: 4.78 against 3.88 ms), and four rows walk in step, so lengths far apart waste slots.
+    bool wave_rows = false;
+    if (sane && !window_ok && (merge_probe & 2)) {
+        int hl = 0, hr = 0;
+        head_row(hl, hr);
+        const int prow = min(panel_rows, rows - p * panel_rows);
+        wave_rows = (hl > 0 && 5 * head_adj >= 2 * hl) || (float)mlen * (float)prow > 2.0f * (float)nnz + 16.0f * (float)prow;
+    }
     if (lane == 0) {
         info[p] = last >= first ? make_int2(first, last) : make_int2(1, 0);
         const int c = mfma ? (window_ok ? PANEL_MFMA_W : PANEL_MFMA_D) : (window_ok ? PANEL_WINDOW : PANEL_DIRECT);
-        cls[p] = c | (shared ? PANEL_SHARED_ROWS : 0) | (phase << PANEL_PHASE_SHIFT);
+        cls[p] = c | (shared ? PANEL_SHARED_ROWS : 0) | (phase << PANEL_PHASE_SHIFT) | (wave_rows ? PANEL_WAVE_ROWS : 0);
         // the middle panel's column span: the direct kernels take it as the band width of the matrix when they choose
         // their panel -> XCD map (one writer)
         if (p == npanels / 2) tail[TAIL_BAND] = last >= first ? last - first + 1 : 0;
@@ -572,16 +589,29 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
     __shared__ int counts[4];
     if (threadIdx.x < 4) counts[threadIdx.x] = 0;
     __syncthreads();
+    // (one workgroup, so the loads are what it waits for: eight panels' verdicts in flight per thread -- a million-row
+    //  matrix has ten thousand panels, and the vote took 33 us with one at a time)
+    constexpr int VU = 8;
     int mine = 0, all = 0, beyond = 0, groups = 0;
-    for (int p = threadIdx.x; p < npanels; p += 1024) {
-        const int2 sp = info[p];
-        const int w = cls[p], c = w & PANEL_CLASS_MASK;
-        if (sp.x <= sp.y) {
-            ++all;
-            mine += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
-            if (c == PANEL_DIRECT || c == PANEL_MFMA_D) {
-                ++beyond;
-                groups += (w & PANEL_SHARED_ROWS) != 0;
+    for (int p0 = threadIdx.x; p0 < npanels; p0 += VU * 1024) {
+        int2 sp[VU];
+        int w[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int p = p0 + u * 1024;
+            sp[u] = p < npanels ? info[p] : make_int2(1, 0);
+            w[u] = p < npanels ? cls[p] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int c = w[u] & PANEL_CLASS_MASK;
+            if (sp[u].x <= sp[u].y) {
+                ++all;
+                mine += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
+                if (c == PANEL_DIRECT || c == PANEL_MFMA_D) {
+                    ++beyond;
+                    groups += (w[u] & PANEL_SHARED_ROWS) != 0;
+                }
             }
         }
     }
@@ -600,34 +630,49 @@ __global__ __launch_bounds__(1024) void mfma_vote_kernel(int npanels, int *__res
     __syncthreads();
     // the direct kernel's panels after the vote: do their rows share column patterns?  (half of them: the row-merging
     // kernel takes all of the call's direct panels, otherwise the row-per-wave kernel does)
-    int direct = 0, shared = 0, left = 0;
+    int direct = 0, shared = 0, left = 0, by_wave = 0;
     bool any_direct = false;
-    for (int p = threadIdx.x; p < npanels; p += 1024) {
-        int c = cls[p] & PANEL_CLASS_MASK;
-        const int flag = cls[p] & ~PANEL_CLASS_MASK; // shared-rows flag and group phase stay
-        if (demote || (to_merge && c == PANEL_MFMA_D)) {
-            if (c == PANEL_MFMA_W) c = PANEL_WINDOW;
-            if (c == PANEL_MFMA_D) {
-                c = PANEL_DIRECT;
-                any_direct = true;
-            }
-            cls[p] = c | flag;
+    for (int p0 = threadIdx.x; p0 < npanels; p0 += VU * 1024) {
+        int2 sp[VU];
+        int w[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int p = p0 + u * 1024;
+            sp[u] = p < npanels ? info[p] : make_int2(1, 0);
+            w[u] = p < npanels ? cls[p] : PANEL_WINDOW;
         }
-        left += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
-        const int2 sp = info[p];
-        if (c == PANEL_DIRECT && sp.x <= sp.y) {
-            ++direct;
-            shared += (flag & PANEL_SHARED_ROWS) != 0;
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int p = p0 + u * 1024;
+            int c = w[u] & PANEL_CLASS_MASK;
+            const int flag = w[u] & ~PANEL_CLASS_MASK; // shared-rows flag and group phase stay
+            if (p < npanels && (demote || (to_merge && c == PANEL_MFMA_D))) {
+                if (c == PANEL_MFMA_W) c = PANEL_WINDOW;
+                if (c == PANEL_MFMA_D) {
+                    c = PANEL_DIRECT;
+                    any_direct = true;
+                }
+                cls[p] = c | flag;
+            }
+            left += c == PANEL_MFMA_W || c == PANEL_MFMA_D;
+            if (c == PANEL_DIRECT && sp[u].x <= sp[u].y) {
+                ++direct;
+                shared += (flag & PANEL_SHARED_ROWS) != 0;
+                by_wave += (flag & PANEL_WAVE_ROWS) != 0;
+            }
         }
     }
     atomicAdd(&counts[2], direct);
     atomicAdd(&counts[3], shared);
     atomicAdd(&counts[0], left);
+    atomicAdd(&counts[1], by_wave);
     if (any_direct) tail[TAIL_DIRECT_EPOCH] = epoch; // (every writer stores the same value)
     __syncthreads();
     if (threadIdx.x == 0) {
         if (counts[0] == 0) tail[TAIL_MFMA_EPOCH] = 0; // nothing for the matrix-core kernel (any more)
         if (counts[2] > 0 && 2 * counts[3] >= counts[2]) tail[TAIL_MERGE_EPOCH] = epoch;
+        // ... else four rows per wave, unless half of them asked for a row per wave (classify_panel)
+        else if (counts[2] > 0 && 2 * counts[1] < counts[2]) tail[TAIL_ROWS_EPOCH] = epoch;
     }
 }
 // no panel of this call is left to the direct kernel (every workgroup asks this first: two scalar loads, no per-panel work)
@@ -1475,7 +1520,8 @@ __global__ __launch_bounds__(WIDE_WAVES * 64) void spmm_direct_dpp_kernel(
     // every panel windowed (the bench matrix): one scalar load of one shared address and out, instead of two
     // dependent loads per workgroup (4500 workgroups of early exits took 16 us of a 340 us step)
     if (cls != nullptr && nothing_direct(tail, epoch)) return;
-    if (GROUPS == 1 && cls != nullptr && tail[TAIL_MERGE_EPOCH] == epoch) return; // the row-merging kernel's call
+    // the row-merging kernel's call, or the four-rows-per-wave kernel's
+    if (GROUPS == 1 && cls != nullptr && (tail[TAIL_MERGE_EPOCH] == epoch || tail[TAIL_ROWS_EPOCH] == epoch)) return;
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     // interleave: neighbouring panels on different XCDs, so that the whole chip sweeps one band of B at a time (wide
@@ -1867,7 +1913,8 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
 // 64-lane chunk load, a reduction and a C write of its own: 0.8 ms for a million such rows at N = 64 (17 % of the
 // HBM time).  Here lane k of DPP row q holds entry k of row 4w+q, step k serves the k-th nonzero of four rows at once,
 // a lane accumulates four columns of its row (two 16-byte loads per step), and a workgroup writes 64 rows of C.
-// Used for the direct panels when the matrix averages fewer than 32 nonzeros per row.
+// Used for the direct panels when the matrix averages fewer than 56 (64 staged columns) / 32 (128+) nonzeros per row, and
+// from 128 staged columns on wherever the classifier's vote prefers it to a row per wave (classify_panel).
 // ---------------------------------------------------------------------------------------------
 constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
 constexpr int ROWS_LONG = 512; // entries from which a row is computed by the whole workgroup
@@ -1875,11 +1922,12 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
-    int info_panel_rows, int interleave, int epoch)
+    int info_panel_rows, int interleave, int epoch, int voted)
 {
     __shared__ double ctile[64][ROWS_PANEL + 1];
     __shared__ int row_mine[ROWS_PANEL];
     if (cls != nullptr && nothing_direct(tail, epoch)) return;
+    if (voted && tail[TAIL_ROWS_EPOCH] != epoch) return; // (128+ staged columns: the vote gave the call to another direct kernel)
     const int lane = threadIdx.x & 63;
     const int wave = wave_uniform(threadIdx.x >> 6);
     const int k = lane & 15, q = lane >> 4;
@@ -2430,15 +2478,22 @@ static float window_min_density(int panel_rows) { return options().window_densit
 // an LDS-tiled launch that every workgroup leaves at once and the per-row ownership test of the direct kernel cost a
 // 1 M-row matrix of 5 nonzeros per row 0.23 ms of a 0.09 ms product (N = 8).
 static float window_min_rowlen(int64_t ldbt);
-bool narrow_classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt)
+// what the classifier looks at for the direct kernels' sake (128+ staged columns): bit 0 rows that share column patterns
+// (row-merging kernel), bit 1 column runs / row-length spread (row per wave or four rows per wave)
+static int direct_probe(int64_t ldbt) { return ldbt >= 128 ? (options().direct_merge ? 3 : 2) : 0; }
+bool classify_worthwhile(int64_t rows, int64_t nnz, int64_t ldbt)
 {
-    return ldbt >= 64 || (rows > 0 && (double)nnz >= 0.75 * (double)window_min_rowlen(ldbt) * (double)rows);
+    // (128+ staged columns: the classifier also feeds the matrix-core and row-merging choices; a forced matrix-core run
+    //  needs its verdicts at any width)
+    return ldbt >= 128 || (ldbt >= 64 && options().spmm_variant == SPMM_VARIANT_MFMA) || (rows > 0 && (double)nnz >= 0.75 * (double)window_min_rowlen(ldbt) * (double)rows);
 }
 static float window_min_rowlen(int64_t ldbt)
 {
     const int t = options().tune[1];
-    if (ldbt >= 64) return 0.0f;
     if (t > 1) return (float)t; /* SBLAS_TUNE=*,<nonzeros per row>: threshold sweeps */
+    // 64+ columns, banded rows, 1 M rows, LDS-tiled kernel | four rows per wave (ms): N = 64: 5 per row .737 | .565, 16: .796 | .669,
+    // 24: .849 | .804, 32: .924 | .944, 48: 1.06 | 1.22; N = 256: 16: 3.01 | 2.65, 24: 3.17 | 3.20, 32: 3.41 | 3.76
+    if (ldbt >= 64) return 24.0f;
     // banded rows, 1 M rows, LDS-tiled kernel | lane groups (ms): N = 8: 27 per row .418 | .283, 40: .464 | .377, 60: .524 | .547,
     // 80: .466 | .554; N = 16: 10: .452 | .287, 27: .483 | .540; N = 32: 10: .672 | .553, 27: .711 | 1.04
     return ldbt <= 8 ? 56.0f : ldbt <= 16 ? 20.0f : 16.0f;
@@ -2494,7 +2549,7 @@ hipError_t launch_stage_range(hipStream_t s, int64_t cols, int64_t n, const doub
         const int np = (rows + info_rows - 1) / info_rows;
         hipLaunchKernelGGL(colrange_classify_kernel, dim3((unsigned)((np + 3) / 4 + nparts)), dim3(256), 0, s, nnz, t.parts,
                            nparts, rows, (int)cols, np, info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt),
-                           mfma_min_fill(variant, info_rows, ldbt), (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr,
+                           mfma_min_fill(variant, info_rows, ldbt), direct_probe(ldbt), t.hdr,
                            t.info, t.cls, epoch);
     } else if (!again) {
         hipLaunchKernelGGL(colrange_kernel, dim3(nparts), dim3(256), 0, s, nnz, colidx, t.parts);
@@ -2535,7 +2590,7 @@ hipError_t launch_stage_classify(hipStream_t s, int64_t cols, int64_t n, const d
     hipLaunchKernelGGL(stage_classify_kernel, grid, dim3(256), 0, s, cols, n, B, ldb, Bt, ldbt, stage_blocks, rows, np,
                        info_rows, rowptr, colidx, 1 << 24, window_min_density(info_rows), window_min_rowlen(ldbt),
                        ldbt < 64 ? 2.0f : mfma_min_fill(variant, info_rows, ldbt),
-                       (ldbt >= 128 && options().direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
+                       direct_probe(ldbt), t.hdr, t.info, t.cls, epoch);
     *epoch_out = epoch;
     return hipGetLastError();
 }
@@ -2549,14 +2604,13 @@ size_t plan_tail_bytes(int64_t rows) { return workspace_tail_bytes(rows); }
 hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx, int64_t ldbt,
                       int variant, bool use_range, PlanView *pv)
 {
-    const Options &opt = options();
     const Tail t = tail_at(pv->tail, rows);
     int info_rows = 0, g = 2;
     panel_plan(rows, ldbt, info_rows, g);
     const int np = (rows + info_rows - 1) / info_rows;
     const int epoch = g_epoch.fetch_add(1, std::memory_order_relaxed);
     const float fill = ldbt < 64 ? 2.0f : mfma_min_fill(variant, info_rows, ldbt);
-    const int probe = (ldbt >= 128 && opt.direct_merge) ? 1 : 0;
+    const int probe = direct_probe(ldbt);
     hipError_t e = hipMemsetAsync(t.hdr, 0, TAIL_HDR * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int nparts = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 4095) / 4096, TAIL_PARTS));
@@ -2588,6 +2642,7 @@ hipError_t plan_build(hipStream_t s, int rows, int cols, int64_t nnz, const int 
         pv->n_mfma_d += c == PANEL_MFMA_D;
     }
     pv->merge = ldbt >= 128 && hdr[TAIL_MERGE_EPOCH] == epoch;
+    pv->four_rows = ldbt >= 128 && !pv->merge && hdr[TAIL_ROWS_EPOCH] == epoch;
     pv->use_range = use_range;
     pv->nparts = nparts;
     return hipSuccess;
@@ -2636,8 +2691,10 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         const int *cls = nullptr;
         int info_rows = 1;
         // pre_epoch != 0: launch_stage_classify has classified the panels already
+        // (64 staged columns and short rows throughout: everything goes to the four-rows-per-wave kernel unclassified)
         const bool classified = pv || (variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
-                                       variant != SPMM_VARIANT_DIRECT_MERGE);
+                                       variant != SPMM_VARIANT_DIRECT_MERGE &&
+                                       (pre_epoch != 0 || classify_worthwhile(rows, nnz, ldbt)));
         const bool preclassified = pv || (pre_epoch != 0 && classified);
         const int epoch = pv ? pv->epoch : preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         if (classified) {
@@ -2653,7 +2710,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                                    /* a (row, tile) visit costs what ~8 nonzeros cost in the direct kernel: ask for 8
                                       per row and 128-column tile on average */
                                    window_min_density(info_rows), window_min_rowlen(ldbt), mfma_min_fill(variant, info_rows, ldbt),
-                                   (ldbt >= 128 && opt.direct_merge) ? 1 : 0, t.hdr, t.info, t.cls, epoch);
+                                   direct_probe(ldbt), t.hdr, t.info, t.cls, epoch);
             const bool mfma_possible = mfma_min_fill(variant, info_rows, ldbt) <= 1.0f;
             // matrix-wide decisions before stage 2 (128+ staged columns only: 64-column calls have neither choice)
             if (ldbt >= 128 && !pv)
@@ -2695,12 +2752,14 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         const size_t pad = opt.direct_lds >= 0 ? (size_t)opt.direct_lds : (ldbt == 64 ? 0 : 90000);
         const int interleave = opt.direct_map; // -1: by the span the classifier recorded
         if (!need_direct) {
-        } else if (n > 32 && (variant == SPMM_VARIANT_DIRECT_ROWS || (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < 32.0))) {
-            // short rows: four rows per wave
+        } else if (n > 32 && (variant == SPMM_VARIANT_DIRECT_ROWS ||
+                              (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < (ldbt == 64 ? 56.0 : 32.0)))) {
+            // short rows: four rows per wave (64 staged columns, banded rows, 1 M rows, against the lane-group kernel: 32 per
+            // row 1.08 | 1.14 ms, 48: 1.41 | 1.54, 64: 1.75 | 1.70, 100: 2.57 | 2.49)
             const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
             hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
                                cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
-                               interleave, epoch);
+                               interleave, epoch, 0);
         } else if (ldbt == 64 && n <= 32) {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<4>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
@@ -2715,7 +2774,15 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             // 128-column tiles.  Classified calls launch both direct kernels: the classifier's vote (device side) says
             // whether the rows share column patterns, and the kernel whose call it is not leaves on one scalar load.
             const bool merge = pv ? pv->merge : variant == SPMM_VARIANT_DIRECT_MERGE || (cls != nullptr && opt.direct_merge);
-            const bool plain = pv ? !pv->merge : variant != SPMM_VARIANT_DIRECT_MERGE;
+            const bool plain = pv ? !pv->merge && !pv->four_rows : variant != SPMM_VARIANT_DIRECT_MERGE;
+            // ... and whether four rows per wave on 64-column tiles suit them better than a row per wave on 128-column tiles
+            const bool four = pv ? pv->four_rows : cls != nullptr && variant != SPMM_VARIANT_DIRECT_MERGE;
+            if (four) {
+                const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
+                hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
+                                   cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
+                                   interleave, epoch, pv ? 0 : 1);
+            }
             if (merge) {
                 // rows that share their column pattern (multi-dof FEM): three rows per wave, shared Bt loads
                 const int mp = (rows + MERGE_PANEL - 1) / MERGE_PANEL;
@@ -2739,7 +2806,7 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
         // the 16- / 32-column direct kernel addresses Bt with 32-bit byte offsets
         const bool wide_offsets = ((uint64_t)cols + 1) * (uint64_t)ldbt * 8ull > 0xffffffffull;
         const bool classified = pv || (!wide_offsets && variant != SPMM_VARIANT_DIRECT_DPP && variant != SPMM_VARIANT_DIRECT_ROWS &&
-                                       variant != SPMM_VARIANT_LANES && (pre_epoch != 0 || narrow_classify_worthwhile(rows, nnz, ldbt)));
+                                       variant != SPMM_VARIANT_LANES && (pre_epoch != 0 || classify_worthwhile(rows, nnz, ldbt)));
         const bool preclassified = pv || (pre_epoch != 0 && classified);
         const int epoch = pv ? pv->epoch : preclassified ? pre_epoch : g_epoch.fetch_add(1, std::memory_order_relaxed);
         const int *cls = nullptr;

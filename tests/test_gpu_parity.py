@@ -883,8 +883,10 @@ def test_spmm_panel_census_paths_are_really_taken(env, variant_env, panel_rows_e
     ci2[rp[100]:rp[101]] = ci2[rp[100]:rp[101]][::-1]                     # one descending row in panel 2
     v2[rp[100]:rp[101]] = v2[rp[100]:rp[101]][::-1]
     assert run(rp, ci2, v2, rows, rows) == (9, 0, 1)                      # that panel recomputed, others not
-    rp3, ci3, v3 = synth.random_csr(rows, 5000, 6, seed=3, sorted_rows=True)
+    rp3, ci3, v3 = synth.random_csr(rows, 5000, 30, seed=3, sorted_rows=True)
     assert run(rp3, ci3, v3, rows, 5000) == (0, 10, 0)                    # too sparse over its span: direct kernel
+    rp3, ci3, v3 = synth.random_csr(rows, 5000, 6, seed=3, sorted_rows=True)
+    assert run(rp3, ci3, v3, rows, 5000) == (0, 0, 0)                     # short rows throughout at 64 columns: not even classified
     rp4, ci4, v4 = synth.banded(rows, 500, 400)                           # rows of 500: several windows per (row, tile) visit
     assert run(rp4, ci4, v4, rows, rows) == (10, 0, 0)
 

@@ -9,6 +9,7 @@ one process, median of the rounds), with the panel census and an oracle check of
     qgrid[:rows[:dofs[:hb]]]   Queen-like on a structured 3-D grid (synth.queen_like_grid), 3 unknowns per node and a +-50 000 band unless given
     powerlaw[:rows[:avg[:max]]] webbase-like row lengths (synth.powerlaw)
     uniform:rows:avg           binomial row lengths, columns anywhere (synth.random_csr)
+    stencil:rows:noff:hb:lo:hi:cl  every row picks lo..hi of the same noff offsets (+-hb), each a run of cl columns
 Environment switches of the library can be set per variant as name=ENV1=val1+ENV2=val2."""
 import argparse, os, sys, time
 import numpy as np, torch
@@ -46,6 +47,20 @@ def make(shape):
     elif kind == "powerlaw":
         rows = int(parts[1]) if len(parts) > 1 else 1000000
         rp, ci, v = synth.powerlaw(rows, avg=float(parts[2]) if len(parts) > 2 else 3.0, max_len=int(parts[3]) if len(parts) > 3 else 5000)
+    elif kind == "stencil":   # stencil:rows:noff:half_band:lo:hi:cluster -- every row picks lo..hi of the same noff offsets,
+        rows, noff, hb, lo, hi, cl = (int(x) for x in parts[1:7])   # each a run of `cluster` consecutive columns
+        rng = np.random.Generator(np.random.MT19937(7))
+        offs = np.unique(np.concatenate([[0], (rng.integers(-hb, hb + 1, noff) // cl) * cl]))
+        k = rng.integers(lo, hi + 1, rows)
+        rank = np.argsort(np.argsort(rng.random((rows, len(offs))), axis=1), axis=1)
+        base = (np.arange(rows)[:, None] // cl) * cl + offs[None, :]
+        mask = (rank < k[:, None]) & (base >= 0) & (base + cl <= rows)
+        mask[:, np.searchsorted(offs, 0)] |= ~mask.any(1)
+        rp = np.zeros(rows + 1, np.int64)
+        np.cumsum(mask.sum(1) * cl, out=rp[1:])
+        ci = (base[mask][:, None] + np.arange(cl)[None, :]).reshape(-1).astype(np.int32)
+        rp = rp.astype(np.int32)
+        v = rng.random(len(ci)) * 2.0 - 1.0
     else:
         raise SystemExit("unknown shape " + shape)
     return rows, rp, ci, v
