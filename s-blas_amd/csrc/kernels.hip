@@ -467,8 +467,12 @@ __device__ __forceinline__ void classify_panel(int p, int rows, int cols, int np
             // scattered one to a chunk (80 per row over a +-50 000 band) lose at any fill (50 %: 1.90 ms against 1.33
             // ms); with 4-5 blocks per chunk (grid-structured rows) 32 % fill loses by 8 %, 48 % wins by 23 %.  So:
             // at least two blocks per visited chunk, and from three on 0.84 of the fill threshold is enough.
+            // ... and panels it can take compete with the LDS-tiled kernel, which round 3 made faster: block-structured
+            // rows, N = 128 | 256, matrix cores against LDS tiles: 60 % fill 0.620 | 1.155 ms against 0.587 | 1.124, 70 %:
+            // 0.560 | 1.052 against 0.560 | 1.092, 80 %: 0.534 | 0.998 against 0.597 | 1.112 -- the bar there is 0.68.
             float need = mfma_min_fill;
             bool dense_chunks = true;
+            if (window_ok && mfma_min_fill > 0.0f) need = fmaxf(need, 0.68f);
             if (!window_ok && mfma_min_fill > 0.0f) {
                 dense_chunks = nblk >= 2 * nchunk;
                 if (nblk >= 3 * nchunk) need *= 0.84f;

@@ -39,7 +39,7 @@ def _shapes(synth):
         "sparse": (synth.random_csr(1000, 4000, 7, seed=3, sorted_rows=True, empty_every=9), 4000),   # every panel direct
         "mixed": (mixed, 3000),                                              # both
         "grid": (synth.queen_like_grid(3000, half_band=400), 3000),          # rows in groups of three: row merging at 128+
-        "blocks": (synth.block_structured(1000, nnz_per_row=150, half_band=400, fill=0.6), 1000),     # matrix cores at 128+
+        "blocks": (synth.block_structured(1000, nnz_per_row=150, half_band=400, fill=0.85), 1000),     # matrix cores at 128+
     }
 
 
@@ -230,11 +230,11 @@ def test_nonfinite_flag_of_range_staging_does_not_stick_to_later_column_chunks(e
     """a row block whose call walks two column chunks through the AUTOMATIC range staging (cols >> rows; no
     switch set).  B holds a NaN in the first chunk's columns only (in a row of the range that no nonzero refers to): the
     first chunk's matrix-core panels fall back to the vector kernels, the second chunk's must not -- every staging pass
-    has an epoch of its own.  Block-structured rows (60 % fill) so that the matrix cores are chosen at 128 columns."""
+    has an epoch of its own.  Block-structured rows (85 % fill) so that the matrix cores are chosen at 128 columns."""
     sblas, oracle, torch, dev = env
     from sblas_amd import synth
     rows, K, n, off = 1000, 400000, 256, 200004          # (a multiple of 4: the 16 x 4 blocks stay aligned)
-    rp, ci, v = synth.block_structured(rows, nnz_per_row=150, half_band=400, fill=0.6)
+    rp, ci, v = synth.block_structured(rows, nnz_per_row=150, half_band=400, fill=0.85)
     ci = (ci + off).astype(np.int32)
     A = Dev(torch, dev, rp, ci, v, K)
     lo, hi = int(ci.min()), int(ci.max())
