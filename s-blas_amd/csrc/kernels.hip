@@ -11,7 +11,8 @@
 //   spmm_direct_merge_kernel     ... of matrices whose neighbouring rows share column patterns (multi-dof FEM, 128-column
 //                                tiles): three rows per wave, shared Bt loads
 //   (spmm_mfma_kernel, panels of dense 16 x 4 sub-blocks on the fp64 matrix cores: spmm_mfma.hip)
-//   spmm_direct_rows_kernel      direct panels of short-row matrices (< 32 per row): four rows per wave
+//   spmm_direct_rows_kernel      direct panels of short-row matrices (< 56 per row at 64 columns), and from 128 columns on
+//                                wherever the classifier's vote prefers it: four rows per wave
 //   spmm_rowpanel_narrow_kernel  n <= 8 (sub-wave lane groups; 16 / 32 columns behind SBLAS_SPMM_MIN_LDBT=0)
 //   spmm_rows8_kernel            n <= 8 and rows of 256+ nonzeros on average: a wave per row, eight sums per lane
 // Epilogues and merges
