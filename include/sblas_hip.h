@@ -92,7 +92,8 @@ int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols
                                const int32_t *rowptr, const int32_t *colidx, int64_t n, void **plan_out);
 int sblas_hip_spmm_plan_destroy(void *plan);
 /* out: [0] planned at all (0: empty matrix or a pinned kernel selection -- calls run unplanned), panels for the
- * LDS-tiled [1] / direct [2] / matrix-core [3] kernels, [4] direct panels go to the row-merging kernel, [5] only the
+ * LDS-tiled [1] / direct [2] / matrix-core [3] kernels, [4] which direct kernel at 128+ staged columns (0 row per wave,
+ * 1 row merging, 2 four rows per wave), [5] only the
  * block's column range of B is staged, [6] staged width, [7] rows per panel */
 int sblas_hip_spmm_plan_info(const void *plan, int64_t out[8]);
 int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream,

@@ -336,7 +336,7 @@ int sblas_hip_spmm_plan_info(const void *plan, int64_t out[8])
     if (!plan || !out) return SBLAS_E_INVALID;
     const SpmmPlan *p = static_cast<const SpmmPlan *>(plan);
     out[0] = p->active, out[1] = p->pv.n_window, out[2] = p->pv.n_direct, out[3] = p->pv.n_mfma_w + p->pv.n_mfma_d;
-    out[4] = p->pv.merge, out[5] = p->pv.use_range, out[6] = p->ldbt, out[7] = p->pv.info_rows;
+    out[4] = p->pv.merge ? 1 : p->pv.four_rows ? 2 : 0, out[5] = p->pv.use_range, out[6] = p->ldbt, out[7] = p->pv.info_rows;
     return SBLAS_OK;
 }
 

@@ -237,7 +237,8 @@ class SpmmPlan:
     def info(self):
         out = (C.c_int64 * 8)()
         check(lib().sblas_hip_spmm_plan_info(self.handle, out), "sblas_hip_spmm_plan_info")
-        return dict(active=bool(out[0]), windowed=int(out[1]), direct=int(out[2]), mfma=int(out[3]), merge=bool(out[4]),
+        return dict(active=bool(out[0]), windowed=int(out[1]), direct=int(out[2]), mfma=int(out[3]), merge=out[4] == 1,
+                    four_rows=out[4] == 2,
                     stage_range=bool(out[5]), ldbt=int(out[6]), panel_rows=int(out[7]))
 
     def spmm(self, val, B, ldb, n, alpha, beta, Cmat, ldc, workspace, stream=None, c_offset=0):

@@ -289,3 +289,44 @@ def test_forced_matrix_core_variant_keeps_panels_the_kernel_can_take(env):
     ref = np.zeros(rows * n)
     oracle.spmm_rows(1000, 1064, rows, rows, n, *A.h, Bh, ref, 1.0, 0.0)
     assert close(C.cpu().numpy().reshape(n, rows)[:, 1000:1064], ref.reshape(n, rows)[:, 1000:1064])
+
+
+@pytest.mark.parametrize("n", [128, 200])
+def test_direct_kernel_vote_at_128_columns(env, n):
+    """Round 3: from 128 staged columns on the call's direct panels go to the four-rows-per-wave kernel unless half of
+    them show column runs (or row lengths far apart) -- then a row per wave on 128-column tiles keeps them; rows in groups
+    of three equal patterns still go to the row-merging kernel.  The plan reports the verdict; planned and unplanned calls
+    agree bit for bit and with the oracle either way."""
+    sblas, oracle, torch, dev = env
+    from sblas_amd import synth
+    rng = np.random.default_rng(5)
+    rows = 3000
+    # (a) banded-random rows, 40 per row over +-1200 columns: no runs -> four rows per wave
+    a = synth.banded(rows, 40, 1200)
+    # (b) clusters of three consecutive columns at scattered offsets, every row its own choice (Queen-like): runs -> row per wave
+    b = synth.queen_like(rows, half_band=1200)
+    # (c) rows of very different lengths (one in eight is ten times the others): lengths far apart -> row per wave
+    lens = np.where(np.arange(rows) % 8 == 0, 400, 40)
+    rp = np.zeros(rows + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    ci = np.concatenate([np.sort(rng.choice(rows, l, replace=False)) for l in lens]).astype(np.int32)
+    c = (rp.astype(np.int32), ci, rng.standard_normal(len(ci)))
+    # (d) grid-structured rows, three unknowns per node: row merging
+    d = synth.queen_like_grid(rows, half_band=400)
+    for name, (rp_, ci_, v_), want in (("banded", a, "four_rows"), ("clusters", b, None), ("skewed", c, None), ("grid", d, "merge")):
+        m = len(rp_) - 1
+        A = Dev(torch, dev, rp_, ci_, v_, m)
+        Bh, C0 = rng.standard_normal(m * n), rng.standard_normal(m * n)
+        B = torch.from_numpy(Bh).to(dev)
+        ws = torch.empty(sblas.spmm_workspace_bytes(m, m, len(ci_), n) // 8, dtype=torch.float64, device=dev)
+        plan = sblas.SpmmPlan(m, m, A.rowptr, A.colidx, n)
+        info = plan.info()
+        assert info["active"] and info["direct"] > 0, (name, info)
+        assert info["four_rows"] == (want == "four_rows") and info["merge"] == (want == "merge"), (name, info)
+        Cu, Cp = torch.from_numpy(C0.copy()).to(dev), torch.from_numpy(C0.copy()).to(dev)
+        sblas.spmm(m, m, A.rowptr, A.colidx, A.val, B, m, n, 0.5, 2.0, Cu, m, ws)
+        plan.spmm(A.val, B, m, n, 0.5, 2.0, Cp, m, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(Cu, Cp), name
+        assert close(Cp.cpu().numpy(), oracle.spmm(m, m, n, *A.h, Bh, C0.copy(), 0.5, 2.0)), name
+        plan.destroy()
