@@ -73,7 +73,7 @@ def merge(prefix, path, command, workload):
                 per[k][c] = sum(v) / len(v)
     if not per:
         return
-    doc = json.load(open(path)) if os.path.exists(path) else {"kernels": {}}
+    doc = {"kernels": {}}   # (one run, one source fingerprint: kernels of earlier collections do not linger)
     doc["command"] = command
     doc["source_sha16"] = source_sha16()
     doc.setdefault("workload", workload)
