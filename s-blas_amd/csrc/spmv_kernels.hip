@@ -257,18 +257,23 @@ __global__ __launch_bounds__(256) void spmv_csr_seg_kernel(int rows, const int *
 // SpMV for long rows, x window in LDS (second attempt).  Diagnostics on the plain kernel: the A stream alone runs at
 // 6.8 TB/s with the same row-per-wave shape (tools/stream_bench.hip), replacing the gather by a one-line read still
 // leaves 76 us -- what costs is the second, dependent vector-memory access per slice (address unit ~15 cycles per
-// instruction, more for a 40-line gather).  Here a 16-row block (one row per wave) fetches the x range its rows span
+// instruction, more for a 40-line gather).  Here an 8-row block (one row per wave; 16 rows in round 2) fetches the x range its rows span
 // into LDS once and gathers from there; the stream loads of a row (up to 448 nonzeros) are issued right after its row
 // pointers, BEFORE the window is known, so the block-wide min/max, the window load and their three barriers hide
 // behind the HBM latency of the stream (the barriers are `s_barrier` without the vmcnt(0) of __syncthreads).
 // Columns outside the window (unsorted rows) are fetched from global memory lane by lane.
 // ---------------------------------------------------------------------------------------------
-constexpr int SPMV_LDS_ROWS = 16;   // = waves per block
-constexpr int SPMV_LDS_CAP = 5120;  // doubles (40 KiB): two blocks per CU
+// Eight waves per block and 36 KiB of window: FOUR blocks per CU, each in another phase of its life (row pointers, stream
+// in flight, window fetch, gathers, reduction), so that the CU's HBM requests do not come in two bursts.  Sixteen waves and
+// 40 KiB (two blocks per CU, round 2): bench matrix 68.3 us against 63.5-64.1 us now; 600 k banded rows of 160 / 260: 345 /
+// 489 us against 337 / 470; 300 k rows of 500 over +-3000 (span beyond the window either way): 529 against 489.
+constexpr int SPMV_LDS_ROWS = 8;    // = waves per block
+constexpr int SPMV_LDS_THREADS = SPMV_LDS_ROWS * 64;
+constexpr int SPMV_LDS_CAP = 4608;  // doubles (36 KiB): four blocks per CU
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int RW, int S> // RW rows per wave (16 RW rows per block), S slices of 64 nonzeros fetched ahead per row
-__global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, const int *__restrict__ rowptr,
+__global__ __launch_bounds__(SPMV_LDS_THREADS) void spmv_csr_lds_kernel(int rows, int cols, const int *__restrict__ rowptr,
                                                            const int *__restrict__ colidx,
                                                            const double *__restrict__ val,
                                                            const double *__restrict__ x, double alpha, double beta,
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, 
     const int pairs = (wlen + 1) >> 1;
     if (wlen > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && lo + 2 * pairs <= cols) {
         const char *src = reinterpret_cast<const char *>(x + lo);
-        for (int p0 = wave * 64; p0 < pairs; p0 += 1024) { // (wave-uniform trip count)
+        for (int p0 = wave * 64; p0 < pairs; p0 += SPMV_LDS_THREADS) { // (wave-uniform trip count)
             const int pr = min(p0 + lane, pairs - 1);  // clamped lanes rewrite the last pair into the slack area
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)pr * 16),
                                              (__attribute__((address_space(3))) void *)(xs + 2 * p0), 16, 0, 0);
@@ -347,13 +352,13 @@ __global__ __launch_bounds__(1024) void spmv_csr_lds_kernel(int rows, int cols, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (wlen > 0) {
         // the whole window in one burst of loads (clamped indices), then the stores
-        constexpr int PASSES = SPMV_LDS_CAP / 1024;
+        constexpr int PASSES = SPMV_LDS_CAP / SPMV_LDS_THREADS;
         double t[PASSES];
 #pragma unroll
-        for (int j = 0; j < PASSES; ++j) t[j] = x[lo + min(tid + 1024 * j, wlen - 1)];
+        for (int j = 0; j < PASSES; ++j) t[j] = x[lo + min(tid + SPMV_LDS_THREADS * j, wlen - 1)];
 #pragma unroll
         for (int j = 0; j < PASSES; ++j)
-            if (tid + 1024 * j < wlen) xs[tid + 1024 * j] = t[j];
+            if (tid + SPMV_LDS_THREADS * j < wlen) xs[tid + SPMV_LDS_THREADS * j] = t[j];
     }
     lds_barrier();
 #pragma unroll
@@ -431,7 +436,7 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
     do {                                                                                                             \
         raise_dynamic_lds((const void *)spmv_csr_lds_kernel<RWV, SV>, (SPMV_LDS_CAP + 128) * sizeof(double));        \
         hipLaunchKernelGGL((spmv_csr_lds_kernel<RWV, SV>),                                                           \
-                           dim3((unsigned)((rows + SPMV_LDS_ROWS * RWV - 1) / (SPMV_LDS_ROWS * RWV))), dim3(1024),    \
+                           dim3((unsigned)((rows + SPMV_LDS_ROWS * RWV - 1) / (SPMV_LDS_ROWS * RWV))), dim3(SPMV_LDS_THREADS),    \
                            (SPMV_LDS_CAP + 128) * sizeof(double), s, rows, cols, rowptr, colidx, val, x, alpha, beta, y); \
         return hipGetLastError();                                                                                    \
     } while (0)
