@@ -33,6 +33,14 @@ struct DeviceScope {
 };
 
 inline int spmm_variant() { return sblas::options().spmm_variant; }
+// the device a `dev` argument means (dev < 0: the calling thread's current device); -1 when that cannot be told
+inline int resolve_device(int dev)
+{
+    if (dev >= 0) return dev;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return -1;
+    return cur;
+}
 
 inline bool csr_args_ok(int64_t rows, int64_t cols, int64_t nnz, const void *rowptr, const void *colidx,
                         const void *val)
@@ -293,7 +301,7 @@ int sblas_hip_spmm_plan_create(int dev, void *stream, int64_t rows, int64_t cols
 {
     if (!plan_out || !csr_args_ok(rows, cols, nnz, rowptr, colidx, reinterpret_cast<const void *>(1)) || n < 0) return SBLAS_E_INVALID;
     SpmmPlan *p = new SpmmPlan;
-    p->dev = dev, p->rows = rows, p->cols = cols, p->nnz = nnz, p->n = n, p->rowptr = rowptr, p->colidx = colidx;
+    p->dev = resolve_device(dev), p->rows = rows, p->cols = cols, p->nnz = nnz, p->n = n, p->rowptr = rowptr, p->colidx = colidx;
     *plan_out = p;
     const int v = spmm_variant();
     const bool classified = v == sblas::SPMM_VARIANT_AUTO || v == sblas::SPMM_VARIANT_MFMA || v == sblas::SPMM_VARIANT_NO_MFMA;
@@ -348,7 +356,9 @@ int sblas_hip_spmm_csr_f64_i32_planned(const void *plan, int dev, void *stream, 
     if (!plan) return SBLAS_E_INVALID;
     const SpmmPlan *p = static_cast<const SpmmPlan *>(plan);
     // the plan speaks for ONE structure: the same arrays it was made from (their contents are the caller's promise)
-    if (p->rows != rows || p->cols != cols || p->nnz != nnz || p->rowptr != rowptr || p->colidx != colidx) return SBLAS_E_INVALID;
+    // ... on the device its verdicts live on
+    if (p->dev != resolve_device(dev) || p->rows != rows || p->cols != cols || p->nnz != nnz || p->rowptr != rowptr || p->colidx != colidx)
+        return SBLAS_E_INVALID;
     return spmm_impl(dev, stream, rows, cols, nnz, rowptr, colidx, val, B, ldb, n, alpha, beta, C, ldc, workspace, workspace_bytes, p);
 }
 
