@@ -120,6 +120,12 @@ def test_plan_follows_new_values_and_refuses_another_structure(env):
                                                     C_.c_void_p(C.data_ptr()), rows, n, 1.0, 0.0, C_.c_void_p(C.data_ptr()), rows,
                                                     C_.c_void_p(ws.data_ptr()), ws.numel() * 8)
         sblas.check(rc, "planned call on another structure")
+    with pytest.raises(sblas.SblasError):                               # ... nor another device's
+        rc = lib.sblas_hip_spmm_csr_f64_i32_planned(plan.handle, 7, None, rows, rows, len(ci), C_.c_void_p(A.rowptr.data_ptr()),
+                                                    C_.c_void_p(A.colidx.data_ptr()), C_.c_void_p(A.val.data_ptr()),
+                                                    C_.c_void_p(C.data_ptr()), rows, n, 1.0, 0.0, C_.c_void_p(C.data_ptr()), rows,
+                                                    C_.c_void_p(ws.data_ptr()), ws.numel() * 8)
+        sblas.check(rc, "planned call on another device")
     plan.destroy()
     # nothing to plan: an empty matrix gives an inactive plan whose calls run the ordinary path
     empty = Dev(torch, dev, np.zeros(11, np.int32), np.zeros(0, np.int32), np.zeros(0), 6)
