@@ -805,6 +805,11 @@ __device__ __forceinline__ void window_select6(int wc, double wv, int tile_lo, i
     gv = __hiloint2double(ghi, glo);
 }
 // the four 32-entry windows of a group: col_idx and val, entries 0-15 (A) and 16-31 (B) of every row
+// NB the loads are asynchronous and the compiler does not know it: between this statement and the window_wait6 that retires
+// them nothing may make it COPY the four registers (a copy made before the wait reads stale data).  The kernels keep the
+// fetch as the last statement of a visit and the wait as the first of the next, which has held on every build so far;
+// moving the fetch ahead of the narrow kernel's FMA block (round 3: to run its round trip under the LDS reads) made the
+// register allocator put v_mov copies in front of the wait -- wrong results on the first parity case, not kept.
 __device__ __forceinline__ void window_issue6(sblas_rsrc_t rc, sblas_rsrc_t rv, int idx, int &ca, double &va, int &cb,
                                               double &vb)
 {
