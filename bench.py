@@ -237,7 +237,7 @@ def bench_spmv(args, torch, S, dev, dist, world, rank, name, rows, cols, nnz, rp
             raise SystemExit("spmv bench result mismatch")
         avg = nnz / max(rows, 1)
         sp_kernel = ("spmv_csr_lds_kernel" if avg > 96 else "spmv_csr_seg_kernel" if avg > 48 else
-                     "spmv_csr_stream_kernel" if avg > 5 else "spmv_csr_kernel")
+                     "spmv_csr_stream_kernel" if avg > 2.5 else "spmv_csr_kernel")
         sp_traffic, sp_src = (measured_traffic(sp_kernel, rows, nnz, 1)
                               if os.environ.get("SBLAS_SPMV_VARIANT", "") in ("", "auto") else (None, None))
         out = {"metric": "SpMV GFLOP/s (2*nnz/t), CSR fp64", "value": round(world * 2.0 * nnz * args.steps / elapsed / 1e9, 2),

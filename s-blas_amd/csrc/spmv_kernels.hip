@@ -98,9 +98,14 @@ __global__ __launch_bounds__(256) void spmv_csr_kernel(int rows, const int *__re
 // the LDS can take (longer rows among the short ones) takes its rows in several runs.
 // ---------------------------------------------------------------------------------------------
 constexpr int ST_ROWS = 256;
-constexpr int ST_CAP = 6144; // products per block (48 KiB + skew): three blocks per CU
+// ST_CAP = products per block held in LDS: 6144 (48 KiB + skew: three blocks per CU) or 4096 (33 KiB: four).  A block walks
+// its 256 rows in runs of up to ST_CAP products, and a block in its summing phase issues no loads, so what pays is the fewest
+// runs first and the most blocks per CU second (round 3; 1 M banded rows of 7 / 13 / 27 per row: 29.5 / 43.6 / 97.1 us with
+// 6144 against 24.2 / 36.6 / 82 us with 4096; 600 k rows of 48, three runs instead of two: 128 against 141 us): the
+// launcher picks per call from the average row length (stream_cap).
 constexpr int ST_LONG = 96;  // rows longer than this are summed by a whole wave
 __device__ __forceinline__ int st_skew(int q) { return q + (q >> 5); } // rows of equal length: spread the LDS banks
+template <int ST_CAP>
 __global__ __launch_bounds__(ST_ROWS) void spmv_csr_stream_kernel(int rows, const int *__restrict__ rowptr,
                                                                  const int *__restrict__ colidx,
                                                                  const double *__restrict__ val,
@@ -415,6 +420,20 @@ __global__ __launch_bounds__(SPMV_LDS_THREADS) void spmv_csr_lds_kernel(int rows
 }
 
 
+// the stream kernel with the LDS capacity that gives a block of average rows the fewest runs; a tie goes to the smaller one
+static hipError_t launch_stream(hipStream_t s, int rows, double avg, const int *rowptr, const int *colidx, const double *val,
+                                const double *x, double alpha, double beta, double *y)
+{
+    const double per_block = avg * ST_ROWS;
+    const int runs4 = (int)((per_block + 4095.0) / 4096.0), runs6 = (int)((per_block + 6143.0) / 6144.0);
+    const dim3 grid((unsigned)((rows + ST_ROWS - 1) / ST_ROWS));
+    if (runs4 <= runs6)
+        hipLaunchKernelGGL(spmv_csr_stream_kernel<4096>, grid, dim3(ST_ROWS), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    else
+        hipLaunchKernelGGL(spmv_csr_stream_kernel<6144>, grid, dim3(ST_ROWS), 0, s, rows, rowptr, colidx, val, x, alpha, beta, y);
+    return hipGetLastError();
+}
+
 template <int LPR>
 static hipError_t spmv_go(hipStream_t s, int rows, const int *rowptr, const int *colidx, const double *val,
                           const double *x, double alpha, double beta, double *y)
@@ -467,11 +486,11 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
         // 128 / 194; 1 M banded rows of 55 / 70: 207 / 256 us vs 250 / 281 us segmented; Queen-like rows of 73: 251 vs
         // 256 us).  Rows beyond 96 take the kernel's slow path (a wave per row), so it stops where a spread of row
         // lengths starts to reach that: Poisson rows of 60 on average tie, of 70 lose 4 %, of 80 7 %, of 90 27 % -- the launcher
-        // only knows the average.  At 5 and below the lanes-per-row kernel is as fast or faster.
-        if (avg > 5.0) {
-            hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0,
-                               s, rows, rowptr, colidx, val, x, alpha, beta, y);
-            return hipGetLastError();
+        // only knows the average.  Round 3 (four blocks per CU for short rows): 2 M uniform rows of 3 / 5: 35.9 / 40.0 us
+        // against 34.6-36.1 / 50.0 us for the lanes-per-row kernel, power-law rows averaging 3.2: 55.7 against 67 us -- the
+        // stream form from 2.5 per row on (round 2: from 5).
+        if (avg > 2.5) {
+            return launch_stream(s, rows, avg, rowptr, colidx, val, x, alpha, beta, y);
         }
         return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
     }
@@ -487,9 +506,7 @@ hipError_t launch_spmv(hipStream_t s, int rows, int cols, int64_t nnz, const int
 #undef SBLAS_SPMV_LDS
 #undef SBLAS_SPMV_SEG
     if (is("stream")) {
-        hipLaunchKernelGGL(spmv_csr_stream_kernel, dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS)), dim3(ST_ROWS), 0, s,
-                           rows, rowptr, colidx, val, x, alpha, beta, y);
-        return hipGetLastError();
+        return launch_stream(s, rows, avg, rowptr, colidx, val, x, alpha, beta, y);
     }
     // "plain" (and anything unknown): lanes per row by average length
     if (avg <= 6.0) return spmv_go<4>(s, rows, rowptr, colidx, val, x, alpha, beta, y);
