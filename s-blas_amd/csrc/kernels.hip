@@ -1933,14 +1933,15 @@ __global__ __launch_bounds__(256) void spmm_rowpanel_narrow_kernel(int rows, con
 // Used for the direct panels when the matrix averages fewer than 56 (64 staged columns) / 32 (128+) nonzeros per row, and
 // from 128 staged columns on wherever the classifier's vote prefers it to a row per wave (classify_panel).
 // ---------------------------------------------------------------------------------------------
-constexpr int ROWS_PANEL = 64; // rows per workgroup: 16 waves x 4
 constexpr int ROWS_LONG = 512; // entries from which a row is computed by the whole workgroup
-__global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
+template <int WV> // waves per workgroup (4 WV rows)
+__global__ __launch_bounds__(WV * 64) void spmm_direct_rows_kernel(
     int rows, int cols, int npanels, const int *__restrict__ rowptr, const int *__restrict__ colidx,
     const double *__restrict__ val, const double *__restrict__ Bt, int64_t ldbt, int n, double alpha, double beta,
     double *__restrict__ C, int64_t ldc, const int *__restrict__ tail, const int *__restrict__ cls,
     int info_panel_rows, int interleave, int epoch, int voted)
 {
+    constexpr int ROWS_PANEL = 4 * WV;
     __shared__ double ctile[64][ROWS_PANEL + 1];
     __shared__ int row_mine[ROWS_PANEL];
     if (cls != nullptr && nothing_direct(tail, epoch)) return;
@@ -1980,7 +1981,7 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     // and computed by all sixteen waves together after the sweep (each wave a slice of the row, sums merged in LDS).
     __shared__ int long_rr[ROWS_PANEL];
     __shared__ int n_long;
-    __shared__ double lpart[16][64];
+    __shared__ double lpart[WV][64];
     if (threadIdx.x == 0) n_long = 0;
     __syncthreads();
     if (mine && pend - p > ROWS_LONG) {
@@ -2034,21 +2035,21 @@ __global__ __launch_bounds__(1024) void spmm_direct_rows_kernel(
     for (int i = 0; i < n_long; ++i) { // (workgroup-uniform; no trips for all but a few panels)
         const int lrr = long_rr[i];
         const int pa = rowptr[row0 + lrr], pb = rowptr[row0 + lrr + 1];
-        const int slice = ((pb - pa + 15) / 16 + 63) & ~63; // whole 64-entry chunks per wave
+        const int slice = ((pb - pa + WV - 1) / WV + 63) & ~63; // whole 64-entry chunks per wave
         const int s0 = min(pa + wave * slice, pb), s1 = min(s0 + slice, pb);
         lpart[wave][lane] = row_direct(colidx, val, Bt, (unsigned)ldbt, (unsigned)(col0 + lane), lane, s0, s1);
         __syncthreads();
         if (threadIdx.x < 64) {
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) t += lpart[w][threadIdx.x];
+            for (int w = 0; w < WV; ++w) t += lpart[w][threadIdx.x];
             ctile[threadIdx.x][lrr] = t;
         }
         __syncthreads();
     }
     const int nrows = min(ROWS_PANEL, rows - row0);
     const int ncols = min(64, n - col0);
-    for (int idx = threadIdx.x; idx < 64 * ROWS_PANEL; idx += 1024) {
+    for (int idx = threadIdx.x; idx < 64 * ROWS_PANEL; idx += WV * 64) {
         const int r = idx % ROWS_PANEL, j = idx / ROWS_PANEL;
         if (r < nrows && j < ncols && row_mine[r]) {
             double *dst = C + (int64_t)(col0 + j) * ldc + (row0 + r);
@@ -2691,6 +2692,28 @@ hipError_t launch_stage_planned(hipStream_t s, int64_t cols, int64_t n, const do
     return hipGetLastError();
 }
 
+// the four-rows-per-wave direct kernel.  Workgroups of 4 waves (16 rows) for the shortest rows, 16 waves (64 rows) otherwise:
+// 1 M banded rows of 5 / 10 / 20 / 32 per row, N = 64, 4 | 8 | 16 waves: 0.547 | 0.554 | 0.571, 0.632 | 0.613 | 0.617, 0.973 |
+// 0.936 | 0.912, 1.22 | 1.17 | 1.14 ms; power-law rows averaging 3.2 (a 64-row workgroup waits for its longest row): 0.740 |
+// 0.830 | 0.957 ms.  (SBLAS_TUNE=*,*,*,<4|8|16> pins the size: A/B runs)
+static void launch_direct_rows(hipStream_t s, int rows, int cols, const int *rowptr, const int *colidx, const double *val,
+                               const double *Bt, int64_t ldbt, int n, double alpha, double beta, double *C, int64_t ldc,
+                               const int *hdr, const int *cls, int info_rows, int interleave, int epoch, int voted,
+                               double avg_row)
+{
+    const int pin = options().tune[3];
+    const int wv = pin == 4 || pin == 8 || pin == 16 ? pin : avg_row < 8.0 ? 4 : 16;
+    const int rp = (rows + 4 * wv - 1) / (4 * wv);
+    const dim3 grid((unsigned)rp, (unsigned)(ldbt / 64));
+#define SBLAS_ROWS_GO(WV)                                                                                             \
+    hipLaunchKernelGGL(spmm_direct_rows_kernel<WV>, grid, dim3(WV * 64), 0, s, rows, cols, rp, rowptr, colidx, val, Bt, \
+                       ldbt, n, alpha, beta, C, ldc, hdr, cls, info_rows, interleave, epoch, voted)
+    if (wv == 4) SBLAS_ROWS_GO(4);
+    else if (wv == 8) SBLAS_ROWS_GO(8);
+    else SBLAS_ROWS_GO(16);
+#undef SBLAS_ROWS_GO
+}
+
 hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, const int *rowptr, const int *colidx,
                                 const double *val, const double *Bt, int64_t ldbt, int n, double alpha,
                                 double beta, double *C, int64_t ldc, int variant, int pre_epoch, const PlanView *pv)
@@ -2773,10 +2796,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
                               (variant != SPMM_VARIANT_DIRECT_DPP && avg_row < (ldbt == 64 ? 56.0 : 32.0)))) {
             // short rows: four rows per wave (64 staged columns, banded rows, 1 M rows, against the lane-group kernel: 32 per
             // row 1.08 | 1.14 ms, 48: 1.41 | 1.54, 64: 1.75 | 1.70, 100: 2.57 | 2.49)
-            const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
-            hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
-                               cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
-                               interleave, epoch, 0);
+            launch_direct_rows(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
+                               interleave, epoch, 0, avg_row);
         } else if (ldbt == 64 && n <= 32) {
             if (pad) raise_dynamic_lds((const void *)spmm_direct_dpp_kernel<4>, pad);
             hipLaunchKernelGGL(spmm_direct_dpp_kernel<4>, dim3((unsigned)wide_panels, 1u), dim3(WIDE_WAVES * 64), pad, s,
@@ -2795,10 +2816,8 @@ hipError_t launch_spmm_rowpanel(hipStream_t s, int rows, int cols, int64_t nnz, 
             // ... and whether four rows per wave on 64-column tiles suit them better than a row per wave on 128-column tiles
             const bool four = pv ? pv->four_rows : cls != nullptr && variant != SPMM_VARIANT_DIRECT_MERGE;
             if (four) {
-                const int rp = (rows + ROWS_PANEL - 1) / ROWS_PANEL;
-                hipLaunchKernelGGL(spmm_direct_rows_kernel, dim3((unsigned)rp, (unsigned)(ldbt / 64)), dim3(1024), 0, s, rows,
-                                   cols, rp, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
-                                   interleave, epoch, pv ? 0 : 1);
+                launch_direct_rows(s, rows, cols, rowptr, colidx, val, Bt, ldbt, n, alpha, beta, C, ldc, t.hdr, cls, info_rows,
+                                   interleave, epoch, pv ? 0 : 1, avg_row);
             }
             if (merge) {
                 // rows that share their column pattern (multi-dof FEM): three rows per wave, shared Bt loads
