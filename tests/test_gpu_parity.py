@@ -1188,20 +1188,29 @@ def test_spmv_segmented_rows_per_wave(env, spmv_variant_env, variant, avg):
         assert close(y.cpu().numpy(), oracle.spmv(M, *A.h, xh, yh.copy(), alpha, beta)), (variant, avg, alpha, beta)
 
 
+@pytest.mark.parametrize("cap", [6144, 4096])
 @pytest.mark.parametrize("variant", ["stream", "auto"])
-def test_spmv_stream_runs_and_oversize_rows(env, spmv_variant_env, variant):
-    """The short-row stream kernel parks a block's products in LDS (6144 per run): a block whose 256 rows hold more
-    is taken in several runs, and a single row beyond the capacity is summed by the whole block.  Rows of 21 on
-    average with one block of 40-nonzero rows, one row of 7000 and one of 6144 exactly; the row count is not a
-    multiple of 256."""
+def test_spmv_stream_runs_and_oversize_rows(env, spmv_variant_env, variant, cap):
+    """The short-row stream kernel parks a block's products in LDS (6144 or 4096 per run; the launcher takes the capacity
+    that gives a block of average rows the fewest runs, round 3): a block whose 256 rows hold more is taken in several
+    runs, and a single row beyond the capacity is summed by the whole block.  cap 6144: rows of 21 on average with one
+    block of 40-nonzero rows, one row of 7000 and one of 6144 exactly; cap 4096: rows of 11 on average, a block of
+    30-nonzero rows, one row of 5000 and one of 4096 exactly.  The row count is not a multiple of 256."""
     sblas, oracle, torch, dev = env
     spmv_variant_env(variant)
     rng = np.random.default_rng(5)
     M, K = 2000, 9000
-    lens = rng.integers(0, 20, M)
-    lens[300:560] = 40
-    lens[700] = 7000
-    lens[1500] = 6144
+    if cap == 6144:
+        lens = rng.integers(0, 20, M)
+        lens[300:560] = 40
+        lens[700] = 7000
+        lens[1500] = 6144
+    else:
+        lens = rng.integers(0, 8, M)
+        lens[300:560] = 30
+        lens[700] = 5000
+        lens[1500] = 4096
+    assert (256.0 * lens.sum() / M <= 4096) == (cap == 4096)      # which instantiation the launcher takes
     lens[M - 1] = 3
     rp = np.zeros(M + 1, dtype=np.int32)
     rp[1:] = np.cumsum(lens)
