@@ -5,7 +5,8 @@
 Every case draws a matrix family (banded / scattered / power-law / grid-structured / block-structured / random with
 empty and very long rows), optional damage (unsorted rows, duplicate columns), a row block of it (method-2 style:
 re-based row pointers, C at an offset, ldc > rows), a column count, leading dimensions, alpha / beta (including 0 and
-NaN-filled C with beta = 0), a kernel-selection switch and -- one case in four -- one of the other value / index types.
+NaN-filled C with beta = 0), a kernel-selection switch, -- one fp64 / int32 case in two -- the planned form of the call (bit-identical
+to the unplanned one) and -- one case in four -- one of the other value / index types.
 fp64: 1e-10 relative (north_star), fp32: 1e-4.  Exit status 1 on the first mismatch (the case's parameters are printed,
 `--seed S --only K` replays it)."""
 import argparse, os, sys
@@ -107,6 +108,18 @@ def one_case(case, rng, dev, max_rows):
         nbytes = S.spmm_workspace_bytes(m, cols, len(sub_ci), n)
         ws = torch.full((max(nbytes // 8, 1),), float("nan"), dtype=torch.float64, device=dev)
         S.spmm(m, cols, drp, dci, dv, dB, ldb, n, alpha, beta, dC, ldc, ws if nbytes else None, c_offset=a)
+        if rng.random() < 0.5:
+            # the planned form of the same call (sblas_hip_spmm_plan_*): bit-identical to the unplanned one
+            plan = S.SpmmPlan(m, cols, drp, dci, n)
+            dCp = d(C0.copy())
+            plan.spmm(dv, dB, ldb, n, alpha, beta, dCp, ldc, ws if nbytes else None, c_offset=a)
+            torch.cuda.synchronize()
+            same = torch.equal(dC.view(torch.int64), dCp.view(torch.int64))
+            params["plan"] = plan.info()
+            plan.destroy()
+            if not same:
+                print("MISMATCH planned vs unplanned", params, flush=True)
+                return False
     else:
         nbytes = S.spmm_typed_workspace_bytes(dv.dtype, drp.dtype, m, cols, len(sub_ci), n)
         ws = torch.full((max(nbytes, 1),), 0xFF, dtype=torch.uint8, device=dev)
